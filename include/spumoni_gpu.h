@@ -1,0 +1,143 @@
+/*
+ * spumoni_gpu.h -- C-ABI of libspumoni_gpu.so: the MI355X (gfx950) drop-in for
+ * the `spumoni run` hot path of oma219/spumoni v2.0.9.
+ *
+ * The reference has no plugin/FFI layer; the narrowest seam on its hot path is
+ *     pml_t::matching_statistics(read, len, lengths[, doc_nums])
+ *                                   (/root/reference/src/compute_ms_pml.cpp:730-737)
+ *     ms_t::matching_statistics(read, len, lengths, pointers[, doc_nums])
+ *                                   (src/compute_ms_pml.cpp:795-828)
+ * plus the constructors pml_t(prefix, use_doc, verbose) (:700) / ms_t(...) (:755)
+ * and get_bwt_stats() (:739-741).  This header is the batch form of exactly
+ * that contract: plain pointers and sizes, no C++ / torch / HIP types.  The
+ * C++ mirror of pml_t / ms_t on top of it lives in spumoni_amd/csrc/host/.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SPX_E* code; the
+ *     message is available from spx_last_error() (thread-local).
+ *   - there is NO CPU fallback: if no gfx950 device is usable every entry
+ *     point that needs one fails with SPX_E_NODEVICE.
+ *   - an spx_index lives on ONE device (one process / one host thread per GPU,
+ *     index replicated per GPU -- SURVEY.md 8(e)); queries on one index are
+ *     serialised internally, different indexes are independent.
+ */
+#ifndef SPUMONI_GPU_H
+#define SPUMONI_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_OK 0
+#define SPX_E_ARG (-1)      /* bad argument                                    */
+#define SPX_E_IO (-2)       /* file missing / malformed                        */
+#define SPX_E_NODEVICE (-3) /* no usable HIP device (no CPU fallback exists)   */
+#define SPX_E_HIP (-4)      /* HIP runtime error                               */
+#define SPX_E_FORMAT (-5)   /* index arrays violate a structural invariant     */
+#define SPX_E_UNSUPPORTED (-6)
+
+/* what a query computes: replaces the choice between pml_t and ms_t */
+#define SPX_MODE_PML 0 /* pml_pointers::_query   (compute_ms_pml.cpp:238-340)  */
+#define SPX_MODE_MS 1  /* ms_pointers::_query    (compute_ms_pml.cpp:571-682)  */
+
+typedef struct spx_index spx_index;
+
+/* per-read result of the bin-max classifier (compute_ms_pml.cpp:969-995,
+ * 1150-1176): bins whose max >= max_value_thr, bins below, and the sum of the
+ * bin maxima (the report prints sum/(above+below) and FOUND iff
+ * above/(above+below) > 0.5).                                                */
+typedef struct spx_class {
+    uint64_t sum_max_bin_values;
+    uint32_t bins_above;
+    uint32_t bins_below;
+} spx_class;
+
+/* walk statistics of the last query on an index (ours, for the roofline
+ * model of SURVEY.md 8(d)): characters searched, steps that took the
+ * mismatch branch (:251), steps that took the predecessor branch (:270),
+ * and index touches by kind.                                                 */
+typedef struct spx_walk_stats {
+    uint64_t steps;
+    uint64_t jumps;
+    uint64_t pred_jumps;
+    uint64_t row_loads;   /* landing-row loads (>= steps)                      */
+    uint64_t dir_loads;   /* per-letter directory loads (count table + window) */
+    float kernel_ms;      /* HIP-event time of the walk kernel, last query     */
+} spx_walk_stats;
+
+const char *spx_last_error(void);
+/* number of usable gfx950 devices (0 if none); never fails                   */
+int spx_device_count(void);
+
+/* ---- index construction -------------------------------------------------
+ * Replaces pml_t::pml_t / ms_t::ms_t (compute_ms_pml.cpp:700-721, 755-786).
+ *
+ * spx_index_from_runs: raw per-run arrays as `newscanNT.x` + `pfp_thresholds
+ * -r` write them and as pml_pointers / ms_pointers
+ * consume them (compute_ms_pml.cpp:44-82, 357-402):
+ *   heads  r bytes (0 and 1 both mean terminator, ms_rle_string.hpp:250)
+ *   lens   r run lengths (> 0)
+ *   thr    r raw thresholds (.thr_pos values; zeros are skipped exactly like
+ *          thr_bv's constructor does, thresholds_ds.hpp:421-423)
+ *   ssa/esa  r stored SA samples (val = right ? right-1 : n-1,
+ *          compute_ms_pml.cpp:433) or NULL (PML-only index)
+ *   doc_start/doc_end  r document ids (DocumentArray, doc_array.hpp:22-23) or NULL
+ * `where` says where the arrays live: 0 = host memory, 1 = memory of `device`
+ * (e.g. produced by another GPU library; no host round trip).  The arrays are
+ * not retained.  The flat HBM layout is built ON THE DEVICE.                  */
+spx_index *spx_index_from_runs(const uint8_t *heads, const uint64_t *lens, const uint64_t *thr,
+                               uint64_t r, const uint64_t *ssa, const uint64_t *esa,
+                               const uint64_t *doc_start, const uint64_t *doc_end, int where,
+                               int device);
+/* Same, from the raw files <prefix>.bwt.heads/.bwt.len/.thr_pos (+ .ssa/.esa
+ * when mode == SPX_MODE_MS).  5-byte little-endian records (common.hpp:59-60). */
+spx_index *spx_index_load_raw(const char *prefix, int mode, int device);
+void spx_index_free(spx_index *ix);
+/* get_bwt_stats() (compute_ms_pml.cpp:171-173, 739-741): n = bwt size, r = runs */
+int spx_index_stats(const spx_index *ix, uint64_t *n, uint64_t *r);
+/* bytes of HBM the flat layout occupies                                       */
+int spx_index_device_bytes(const spx_index *ix, uint64_t *bytes);
+/* Text for the MS length extension (ms_t's `ra.charAt`, compute_ms_pml.cpp:805):
+ * the plain text replaces the SLP random-access structure.  where: 0 host, 1 device. */
+int spx_index_set_text(spx_index *ix, const uint8_t *text, uint64_t n_text, int where);
+
+/* ---- queries -------------------------------------------------------------
+ * Batch form of matching_statistics.  seqs = concatenated reads, already
+ * upper-cased / digested by the caller (compute_ms_pml.cpp:916-923), offsets =
+ * nreads+1 offsets into seqs.  All outputs are laid out at the same offsets
+ * (element i of read q at offsets[q]+i), and may be NULL when not wanted:
+ *   out_lengths   PML lengths (PML mode) or MS lengths (MS mode, needs
+ *                 spx_index_set_text; compute_ms_pml.cpp:800-810)
+ *   out_pointers  MS pointers (MS mode only)
+ *   out_docs      document ids (index must have been built with doc arrays)
+ *   out_class     nreads entries, bin-max classifier over out_lengths' values
+ *                 (bin_width in [1, ..]; ignored when out_class is NULL)
+ * Host-buffer form: copies in, runs, copies out, returns when done.          */
+int spx_query_batch(spx_index *ix, int mode, const uint8_t *seqs, const uint64_t *offsets,
+                    uint64_t nreads, uint32_t *out_lengths, uint64_t *out_pointers,
+                    uint32_t *out_docs, spx_class *out_class, uint64_t bin_width,
+                    uint64_t max_value_thr);
+/* Device-buffer form: every pointer is memory of the index's device; the work
+ * is enqueued on `stream` (a hipStream_t passed as void*, NULL = default
+ * stream) and the call returns without synchronising.                        */
+int spx_query_batch_device(spx_index *ix, int mode, const uint8_t *d_seqs,
+                           const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
+                           uint32_t *d_out_lengths, uint64_t *d_out_pointers,
+                           uint32_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                           uint64_t max_value_thr, void *stream);
+/* Statistics + HIP-event kernel time of the most recent query on `ix`
+ * (synchronises with that query).                                            */
+int spx_last_walk_stats(spx_index *ix, spx_walk_stats *out);
+
+/* ---- tuning knobs (optional) --------------------------------------------- */
+/* kernel variant: 0 = auto, 1 = lane-per-read state machine,
+ * 64 = wavefront-per-read                                        */
+int spx_set_option(spx_index *ix, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,239 @@
+"""ctypes binding of libspumoni_gpu.so (the C-ABI in include/spumoni_gpu.h).
+
+This is plumbing for tests and bench: torch only provides device memory and
+streams.  There is no CPU fallback -- if the library or a gfx950 device is
+missing, loading / index construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspumoni_gpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SPX_MODE_PML = 0
+SPX_MODE_MS = 1
+
+EXPORTS = [
+    "spx_last_error",
+    "spx_device_count",
+    "spx_index_from_runs",
+    "spx_index_load_raw",
+    "spx_index_free",
+    "spx_index_stats",
+    "spx_index_device_bytes",
+    "spx_index_set_text",
+    "spx_query_batch",
+    "spx_query_batch_device",
+    "spx_last_walk_stats",
+    "spx_set_option",
+]
+
+
+class SpxClass(C.Structure):
+    _fields_ = [("sum_max_bin_values", C.c_uint64), ("bins_above", C.c_uint32), ("bins_below", C.c_uint32)]
+
+
+class SpxWalkStats(C.Structure):
+    _fields_ = [
+        ("steps", C.c_uint64),
+        ("jumps", C.c_uint64),
+        ("pred_jumps", C.c_uint64),
+        ("row_loads", C.c_uint64),
+        ("dir_loads", C.c_uint64),
+        ("kernel_ms", C.c_float),
+    ]
+
+
+CLASS_DTYPE = np.dtype([("sum_max", "<u8"), ("above", "<u4"), ("below", "<u4")])
+
+
+class SpxError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libspumoni_gpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpxError(
+                f"{LIB_PATH} is missing: build it with `make -C spumoni_amd/csrc` "
+                "(there is no CPU fallback for the HIP path)"
+            )
+        L = C.CDLL(LIB_PATH)
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+        L.spx_last_error.restype = C.c_char_p
+        L.spx_device_count.restype = i32
+        L.spx_index_from_runs.restype = vp
+        L.spx_index_from_runs.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, i32, i32]
+        L.spx_index_load_raw.restype = vp
+        L.spx_index_load_raw.argtypes = [C.c_char_p, i32, i32]
+        L.spx_index_free.argtypes = [vp]
+        L.spx_index_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.spx_index_device_bytes.argtypes = [vp, C.POINTER(u64)]
+        L.spx_index_set_text.argtypes = [vp, vp, u64, i32]
+        L.spx_query_batch.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
+        L.spx_query_batch_device.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
+        L.spx_last_walk_stats.argtypes = [vp, C.POINTER(SpxWalkStats)]
+        L.spx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SpxError(f"spx error {rc}: {lib().spx_last_error().decode()}")
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _t_ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Index:
+    """An spx_index on one GPU."""
+
+    def __init__(self, handle, device: int):
+        self._h = handle
+        self.device = device
+        n, r = C.c_uint64(), C.c_uint64()
+        _check(lib().spx_index_stats(self._h, C.byref(n), C.byref(r)))
+        self.n, self.r = n.value, r.value
+
+    # -- construction -----------------------------------------------------
+    @classmethod
+    def from_raw(cls, raw, device: int = 0) -> "Index":
+        """raw: spumoni_amd.synth.RawIndex (torch tensors on CPU or on `device`)."""
+        import torch
+
+        on_dev = raw.heads.is_cuda
+        keep = []
+
+        def prep(t, dt):
+            if t is None:
+                return None
+            t = t.to(dt).contiguous()
+            keep.append(t)
+            return t
+
+        heads = prep(raw.heads, torch.uint8)
+        # int64 and uint64 share the bit pattern for the value range used here
+        lens, thr = prep(raw.lens, torch.int64), prep(raw.thr, torch.int64)
+        ssa, esa = prep(raw.ssa, torch.int64), prep(raw.esa, torch.int64)
+        ds, de = prep(raw.doc_start, torch.int64), prep(raw.doc_end, torch.int64)
+        if on_dev:
+            torch.cuda.synchronize()
+        h = lib().spx_index_from_runs(
+            _t_ptr(heads), _t_ptr(lens), _t_ptr(thr), raw.r, _t_ptr(ssa), _t_ptr(esa), _t_ptr(ds), _t_ptr(de),
+            1 if on_dev else 0, device,
+        )
+        if not h:
+            raise SpxError(lib().spx_last_error().decode())
+        ix = cls(h, device)
+        if raw.text is not None:
+            ix.set_text(raw.text)
+        return ix
+
+    @classmethod
+    def load_raw(cls, prefix: str, mode: int = SPX_MODE_PML, device: int = 0) -> "Index":
+        h = lib().spx_index_load_raw(prefix.encode(), mode, device)
+        if not h:
+            raise SpxError(lib().spx_last_error().decode())
+        return cls(h, device)
+
+    def set_text(self, text) -> None:
+        t = text.contiguous()
+        _check(lib().spx_index_set_text(self._h, _t_ptr(t), t.numel(), 1 if t.is_cuda else 0))
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            lib().spx_index_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        b = C.c_uint64()
+        _check(lib().spx_index_device_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(lib().spx_set_option(self._h, key.encode(), value))
+
+    # -- queries, host buffers (numpy) --------------------------------------
+    def query_host(self, mode, seqs, offs, want_lengths=True, want_docs=False, classify=None):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        nreads = offs.size - 1
+        tot = int(offs[-1]) if nreads > 0 else 0
+        lens = np.zeros(max(tot, 1), dtype=np.uint32) if want_lengths else None
+        ptrs = np.zeros(max(tot, 1), dtype=np.uint64) if mode == SPX_MODE_MS else None
+        docs = np.zeros(max(tot, 1), dtype=np.uint32) if want_docs else None
+        cls_ = np.zeros(max(nreads, 1), dtype=CLASS_DTYPE) if classify else None
+        bw, thr = classify if classify else (0, 0)
+        _check(lib().spx_query_batch(self._h, mode, _np_ptr(seqs), _np_ptr(offs), nreads, _np_ptr(lens),
+                                     _np_ptr(ptrs), _np_ptr(docs), _np_ptr(cls_), bw, thr))
+        out = {}
+        if lens is not None:
+            out["lengths"] = lens[:tot]
+        if ptrs is not None:
+            out["pointers"] = ptrs[:tot]
+        if docs is not None:
+            out["docs"] = docs[:tot]
+        if cls_ is not None:
+            out["class"] = cls_[:nreads]
+        return out
+
+    # -- queries, device buffers (torch tensors on self.device) -------------
+    def query_device(self, mode, d_seqs, d_offs, total_chars, d_lengths=None, d_pointers=None, d_docs=None,
+                     d_class=None, bin_width=0, max_value_thr=0, stream=None):
+        """Enqueue on `stream` (a torch.cuda.Stream or None = torch's current stream)."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        nreads = d_offs.numel() - 1
+        _check(lib().spx_query_batch_device(
+            self._h, mode, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars, _t_ptr(d_lengths),
+            _t_ptr(d_pointers), _t_ptr(d_docs), _t_ptr(d_class), bin_width, max_value_thr,
+            C.c_void_p(st.cuda_stream)))
+
+    def last_stats(self) -> dict:
+        s = SpxWalkStats()
+        _check(lib().spx_last_walk_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in SpxWalkStats._fields_}
+
+
+def pad_seqs(seqs):
+    """Return a device/host tensor copy of seqs padded to a multiple of 8 (+8) bytes."""
+    import torch
+
+    n = seqs.numel()
+    padded = torch.zeros(((n + 7) // 8) * 8 + 8, dtype=torch.uint8, device=seqs.device)
+    padded[:n] = seqs
+    return padded

@@ -1,0 +1,434 @@
+// spx_api.hip -- the C-ABI of libspumoni_gpu.so (include/spumoni_gpu.h).
+// No CPU fallback exists anywhere in this library: without a gfx950 device every
+// entry point that needs one returns SPX_E_NODEVICE.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "spx_internal.h"
+
+namespace spx {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return SPX_E_HIP;
+}
+
+static int usable_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static int select_device(int device) {
+    const int n = usable_devices();
+    if (n <= 0) {
+        set_error("no HIP device visible: libspumoni_gpu has no CPU fallback");
+        return SPX_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return SPX_E_ARG;
+    }
+    SPX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                  prop.gcnArchName);
+        return SPX_E_NODEVICE;
+    }
+    return SPX_OK;
+}
+
+struct HostFree {
+    void operator()(void* p) const { free(p); }
+};
+
+static bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)sz);
+    bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    fclose(f);
+    return ok;
+}
+
+// 5-byte little-endian records (THRBYTES / SSABYTES, include/common.hpp:59-60)
+static void unpack5(const std::vector<uint8_t>& raw, size_t stride, size_t pick,
+                    std::vector<uint64_t>& out) {
+    const size_t n = raw.size() / (5 * stride);
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t v = 0;
+        memcpy(&v, raw.data() + (i * stride + pick) * 5, 5);
+        out[i] = v;
+    }
+}
+
+}  // namespace spx
+
+using namespace spx;
+
+extern "C" {
+
+const char* spx_last_error(void) { return g_err.c_str(); }
+
+int spx_device_count(void) { return usable_devices(); }
+
+void spx_index_free(spx_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->rows) (void)hipFree(ix->rows);
+    if (ix->cnt) (void)hipFree(ix->cnt);
+    if (ix->q_alloc) (void)hipFree(ix->q_alloc);
+    if (ix->samples) (void)hipFree(ix->samples);
+    if (ix->letters) (void)hipFree(ix->letters);
+    if (ix->text) (void)hipFree(ix->text);
+    if (ix->counters) (void)hipFree(ix->counters);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    delete ix;
+}
+
+static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* lens,
+                          const uint64_t* thr, uint64_t r, const uint64_t* ssa, const uint64_t* esa,
+                          const uint64_t* ds, const uint64_t* de, int where) {
+    if (!heads || !lens || !thr || r == 0) {
+        set_error("heads, lens and thr must be non-null and r > 0");
+        return SPX_E_ARG;
+    }
+    if ((ssa == nullptr) != (esa == nullptr) || (ds == nullptr) != (de == nullptr)) {
+        set_error("ssa/esa and doc_start/doc_end must be given in pairs");
+        return SPX_E_ARG;
+    }
+    ix->r = r;
+    struct Tmp {
+        void* p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } t[7];
+    const void* src[7] = {heads, lens, thr, ssa, esa, ds, de};
+    const void* dev[7];
+    for (int i = 0; i < 7; ++i) {
+        dev[i] = src[i];
+        if (where == 0 && src[i]) {
+            const size_t bytes = (i == 0 ? 1 : 8) * r;
+            SPX_HIP(hipMalloc(&t[i].p, bytes));
+            SPX_HIP(hipMemcpy(t[i].p, src[i], bytes, hipMemcpyHostToDevice));
+            dev[i] = t[i].p;
+        }
+    }
+    int rc = flatten_on_device(ix, (const uint8_t*)dev[0], (const uint64_t*)dev[1],
+                               (const uint64_t*)dev[2], (const uint64_t*)dev[3],
+                               (const uint64_t*)dev[4], (const uint64_t*)dev[5],
+                               (const uint64_t*)dev[6]);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipMalloc((void**)&ix->counters, sizeof(WalkCounters)));
+    SPX_HIP(hipMemset(ix->counters, 0, sizeof(WalkCounters)));
+    SPX_HIP(hipEventCreate(&ix->ev0));
+    SPX_HIP(hipEventCreate(&ix->ev1));
+    SPX_HIP(hipDeviceSynchronize());
+    return SPX_OK;
+}
+
+spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr,
+                               uint64_t r, const uint64_t* ssa, const uint64_t* esa,
+                               const uint64_t* doc_start, const uint64_t* doc_end, int where,
+                               int device) {
+    if (select_device(device) != SPX_OK) return nullptr;
+    if (where != 0 && where != 1) {
+        set_error("where must be 0 (host) or 1 (device)");
+        return nullptr;
+    }
+    spx_index* ix = new spx_index();
+    ix->device = device;
+    if (from_runs_impl(ix, heads, lens, thr, r, ssa, esa, doc_start, doc_end, where) != SPX_OK) {
+        spx_index_free(ix);
+        return nullptr;
+    }
+    return ix;
+}
+
+spx_index* spx_index_load_raw(const char* prefix, int mode, int device) {
+    if (!prefix) {
+        set_error("prefix is null");
+        return nullptr;
+    }
+    const std::string p(prefix);
+    std::vector<uint8_t> heads, raw;
+    std::vector<uint64_t> lens, thr, ssa, esa;
+    if (!read_file(p + ".bwt.heads", heads) || heads.empty()) {
+        set_error("cannot read %s.bwt.heads", prefix);
+        return nullptr;
+    }
+    const uint64_t r = heads.size();
+    if (!read_file(p + ".bwt.len", raw) || raw.size() != r * 5) {
+        set_error("%s.bwt.len missing or not %llu 5-byte records", prefix, (unsigned long long)r);
+        return nullptr;
+    }
+    unpack5(raw, 1, 0, lens);
+    if (!read_file(p + ".thr_pos", raw) || raw.size() != r * 5) {
+        set_error("%s.thr_pos missing or not %llu 5-byte records", prefix, (unsigned long long)r);
+        return nullptr;
+    }
+    unpack5(raw, 1, 0, thr);
+    if (mode == SPX_MODE_MS) {
+        uint64_t n = 0;
+        for (uint64_t v : lens) n += v;
+        for (int which = 0; which < 2; ++which) {
+            const std::string path = p + (which ? ".esa" : ".ssa");
+            if (!read_file(path, raw) || raw.size() != r * 10) {
+                set_error("%s missing or not %llu (left,right) 5-byte pairs", path.c_str(),
+                          (unsigned long long)r);
+                return nullptr;
+            }
+            std::vector<uint64_t>& dst = which ? esa : ssa;
+            unpack5(raw, 2, 1, dst);
+            for (auto& v : dst) v = v ? v - 1 : n - 1;  // compute_ms_pml.cpp:433
+        }
+    }
+    return spx_index_from_runs(heads.data(), lens.data(), thr.data(), r,
+                               ssa.empty() ? nullptr : ssa.data(), esa.empty() ? nullptr : esa.data(),
+                               nullptr, nullptr, 0, device);
+}
+
+int spx_index_stats(const spx_index* ix, uint64_t* n, uint64_t* r) {
+    if (!ix) {
+        set_error("index is null");
+        return SPX_E_ARG;
+    }
+    if (n) *n = ix->n;
+    if (r) *r = ix->r;
+    return SPX_OK;
+}
+
+int spx_index_device_bytes(const spx_index* ix, uint64_t* bytes) {
+    if (!ix || !bytes) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    *bytes = ix->device_bytes + ix->n_text;
+    return SPX_OK;
+}
+
+int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int where) {
+    if (!ix || !text) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    if (ix->text) (void)hipFree(ix->text);
+    ix->text = nullptr;
+    SPX_HIP(hipMalloc((void**)&ix->text, n_text + 16));
+    SPX_HIP(hipMemcpy(ix->text, text, n_text, where ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    ix->n_text = n_text;
+    ix->view.text = ix->text;
+    ix->view.n_text = n_text;
+    return SPX_OK;
+}
+
+int spx_set_option(spx_index* ix, const char* key, int64_t value) {
+    if (!ix || !key) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!strcmp(key, "variant")) {
+        ix->variant = (int)value;
+        return SPX_OK;
+    }
+    if (!strcmp(key, "waves_per_cu")) {
+        ix->waves_per_cu = (int)value;
+        return SPX_OK;
+    }
+    set_error("unknown option '%s'", key);
+    return SPX_E_ARG;
+}
+
+static int check_query(spx_index* ix, int mode, const void* seqs, const void* offs,
+                       uint32_t* out_lengths, uint64_t* out_pointers, uint32_t* out_docs,
+                       spx_class* out_class, uint64_t bin_width) {
+    if (!ix || !seqs || !offs) {
+        set_error("index, seqs and offsets must be non-null");
+        return SPX_E_ARG;
+    }
+    if (mode != SPX_MODE_PML && mode != SPX_MODE_MS) {
+        set_error("mode must be SPX_MODE_PML or SPX_MODE_MS");
+        return SPX_E_ARG;
+    }
+    if (mode == SPX_MODE_PML && !out_lengths) {
+        set_error("PML mode needs out_lengths");
+        return SPX_E_ARG;
+    }
+    if (mode == SPX_MODE_PML && out_pointers) {
+        set_error("out_pointers is only produced in MS mode");
+        return SPX_E_ARG;
+    }
+    if (mode == SPX_MODE_MS) {
+        if (!ix->has_samples) {
+            set_error("MS mode needs an index built with SA samples (.ssa/.esa)");
+            return SPX_E_ARG;
+        }
+        if (!out_pointers) {
+            set_error("MS mode needs out_pointers");
+            return SPX_E_ARG;
+        }
+        if (out_lengths && !ix->text) {
+            set_error("MS lengths need the text: call spx_index_set_text first");
+            return SPX_E_ARG;
+        }
+        if (out_class && !out_lengths) {
+            set_error("MS classification needs out_lengths");
+            return SPX_E_ARG;
+        }
+    }
+    if (out_docs && !ix->has_docs) {
+        set_error("document ids requested but the index has no document array");
+        return SPX_E_ARG;
+    }
+    if (out_class && bin_width == 0) {
+        set_error("bin_width must be > 0");
+        return SPX_E_ARG;
+    }
+    return SPX_OK;
+}
+
+int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
+                           uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
+                           uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
+                           uint64_t bin_width, uint64_t max_value_thr, void* stream) {
+    int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs,
+                         d_out_class, bin_width);
+    if (rc != SPX_OK) return rc;
+    if (((uintptr_t)d_seqs & 7) != 0) {
+        set_error("d_seqs must be 8-byte aligned (and readable up to the next multiple of 8)");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), st));
+    BatchArgs a;
+    a.seqs = d_seqs;
+    a.offs = d_offsets;
+    a.nreads = nreads;
+    a.out_lengths = d_out_lengths;
+    a.out_pointers = d_out_pointers;
+    a.out_docs = d_out_docs;
+    a.out_class = (mode == SPX_MODE_PML) ? d_out_class : nullptr;
+    a.bin_width = bin_width;
+    a.max_value_thr = max_value_thr;
+    a.counters = ix->counters;
+    SPX_HIP(hipEventRecord(ix->ev0, st));
+    if (nreads > 0) {
+        rc = launch_walk(ix, mode, a, total_chars, st);
+        if (rc != SPX_OK) return rc;
+    }
+    SPX_HIP(hipEventRecord(ix->ev1, st));
+    if (mode == SPX_MODE_MS && d_out_lengths && nreads > 0) {
+        a.out_class = d_out_class;
+        rc = launch_ms_extend(ix, a, st);
+        if (rc != SPX_OK) return rc;
+    }
+    ix->have_timing = true;
+    ix->last_stream = st;
+    return SPX_OK;
+}
+
+int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
+                    uint64_t nreads, uint32_t* out_lengths, uint64_t* out_pointers,
+                    uint32_t* out_docs, spx_class* out_class, uint64_t bin_width,
+                    uint64_t max_value_thr) {
+    int rc = check_query(ix, mode, seqs, offsets, out_lengths, out_pointers, out_docs, out_class,
+                         bin_width);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipSetDevice(ix->device));
+    const uint64_t total = nreads ? offsets[nreads] : 0;
+    struct Tmp {
+        void* p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } dseq, doff, dlen, dptr, ddoc, dcls;
+    const uint64_t padded = ((total + 7) / 8) * 8 + 8;
+    SPX_HIP(hipMalloc(&dseq.p, padded));
+    SPX_HIP(hipMemset(dseq.p, 0, padded));
+    SPX_HIP(hipMemcpy(dseq.p, seqs, total, hipMemcpyHostToDevice));
+    SPX_HIP(hipMalloc(&doff.p, (nreads + 1) * 8));
+    SPX_HIP(hipMemcpy(doff.p, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    if (out_lengths) SPX_HIP(hipMalloc(&dlen.p, (total + 1) * 4));
+    if (out_pointers) SPX_HIP(hipMalloc(&dptr.p, (total + 1) * 8));
+    if (out_docs) SPX_HIP(hipMalloc(&ddoc.p, (total + 1) * 4));
+    if (out_class) SPX_HIP(hipMalloc(&dcls.p, (nreads + 1) * sizeof(spx_class)));
+    rc = spx_query_batch_device(ix, mode, (const uint8_t*)dseq.p, (const uint64_t*)doff.p, nreads,
+                                total, (uint32_t*)dlen.p, (uint64_t*)dptr.p, (uint32_t*)ddoc.p,
+                                (spx_class*)dcls.p, bin_width, max_value_thr, nullptr);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipDeviceSynchronize());
+    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen.p, total * 4, hipMemcpyDeviceToHost));
+    if (out_pointers) SPX_HIP(hipMemcpy(out_pointers, dptr.p, total * 8, hipMemcpyDeviceToHost));
+    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc.p, total * 4, hipMemcpyDeviceToHost));
+    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls.p, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    if (wc.error) {
+        set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
+                  "thresholds are inconsistent with the BWT)", wc.error);
+        return SPX_E_FORMAT;
+    }
+    return SPX_OK;
+}
+
+int spx_last_walk_stats(spx_index* ix, spx_walk_stats* out) {
+    if (!ix || !out) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->have_timing) {
+        set_error("no query has run on this index yet");
+        return SPX_E_ARG;
+    }
+    SPX_HIP(hipSetDevice(ix->device));
+    SPX_HIP(hipEventSynchronize(ix->ev1));
+    SPX_HIP(hipStreamSynchronize(ix->last_stream));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    float ms = 0;
+    SPX_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+    out->steps = wc.steps;
+    out->jumps = wc.jumps;
+    out->pred_jumps = wc.pred_jumps;
+    out->row_loads = wc.row_loads;
+    out->dir_loads = wc.dir_loads;
+    out->kernel_ms = ms;
+    if (wc.error) {
+        set_error("the walk hit %llu undefined steps (inconsistent thresholds)", wc.error);
+        return SPX_E_FORMAT;
+    }
+    return SPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// spx_flatten.hip -- builds the flat HBM layout (spx_layout.h) ON THE DEVICE from
+// the raw per-run arrays of the index (heads / lengths / thresholds [/ samples /
+// docs]).  Replaces, for the GPU, what ms_rle_string's RLE constructor
+// (include/ms_rle_string.hpp:217-288), build_F_ (src/compute_ms_pml.cpp:119-147)
+// and thr_bv's constructor (include/thresholds_ds.hpp:384-440) build on the CPU.
+//
+// Everything is a scan, a stable 8-bit radix sort or a per-run gather, so even a
+// 10^9-run index is laid out in seconds without touching the host.
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "spx_internal.h"
+
+namespace spx {
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned nblocks(uint64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+struct DevBuf {  // RAII scratch buffer
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T>
+    T* as() {
+        return (T*)p;
+    }
+};
+
+// heads: 0 -> TERMINATOR(1) (ms_rle_string.hpp:249-253); also validates lens > 0
+__global__ void k_norm_heads(const uint8_t* heads, const uint64_t* lens, uint64_t r, uint8_t* H,
+                             uint32_t* iota, unsigned long long* err) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= r) return;
+    uint8_t c = heads[i];
+    H[i] = c <= 1 ? 1 : c;
+    iota[i] = (uint32_t)i;
+    if (lens[i] == 0 || lens[i] > MASK40) atomicAdd(err, 1ull);
+}
+
+__global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t r, uint64_t* dst) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < r) dst[i] = src[idx[i]];
+}
+
+__global__ void k_nonzero_flag(const uint64_t* thr, const uint32_t* idx, uint64_t r, uint32_t* flag) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < r) flag[i] = thr[idx[i]] != 0 ? 1u : 0u;
+}
+
+// compact the non-zero thresholds in (letter, run) order: what thr_bv stores per letter
+__global__ void k_compact_thr(const uint64_t* thr, const uint32_t* idx, const uint32_t* nzpos,
+                              uint64_t r, uint64_t* T) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= r) return;
+    uint64_t t = thr[idx[i]];
+    if (t != 0) T[nzpos[i]] = t;
+}
+
+__device__ __forceinline__ uint64_t upper_bound_u64(const uint64_t* a, uint64_t n, uint64_t x) {
+    uint64_t lo = 0, hi = n;  // first index with a[idx] > x
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] <= x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// one thread per byte value: directory range, F[c] and where F[c] lands
+__global__ void k_letters(const uint8_t* Hs, const uint64_t* LFs, const uint64_t* S, uint64_t r,
+                          uint64_t n, LetterInfo* out) {
+    __shared__ uint32_t present[256];
+    int c = threadIdx.x;
+    // lower_bound / upper_bound of c in the sorted head array
+    uint64_t lo = 0, hi = r;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (Hs[mid] < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    uint64_t qbeg = lo;
+    hi = r;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (Hs[mid] <= c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    uint64_t qend = lo;
+    present[c] = qend > qbeg ? 1u : 0u;
+    __syncthreads();
+    uint32_t lid = 0;
+    for (int x = 0; x < c; ++x) lid += present[x];
+    // F[c] = number of characters smaller than c = LF image of the first c-run start
+    uint64_t F = qbeg < r ? LFs[qbeg] : n;
+    uint64_t frun = F >= n ? r : upper_bound_u64(S, r, F) - 1;
+    LetterInfo li;
+    li.lid = present[c] ? lid : NO_LETTER;
+    li.qbeg = (uint32_t)qbeg;
+    li.qend = (uint32_t)qend;
+    li.frun = (uint32_t)frun;
+    li.foff = F >= n ? 0 : F - S[frun];
+    li.pad_ = 0;
+    out[c] = li;
+}
+
+// one thread per run, in (letter, run index) order: assemble the 32-byte row
+__global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint64_t* LFs,
+                             const uint64_t* S, const uint64_t* lens, const uint32_t* nzpos,
+                             const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
+                             const uint64_t* de, const LetterInfo* letters, uint64_t r, uint64_t n,
+                             Row* rows, unsigned long long* err) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= r) return;
+    uint32_t k = Qall[i];
+    uint32_t c = Hs[i];
+    LetterInfo li = letters[c];
+    // LF(S[k]) = F[c] + (number of c before run k) = exclusive scan in (letter, run) order
+    uint64_t lf = LFs[i];
+    uint64_t dst = upper_bound_u64(S, r, lf) - 1;
+    // thr_bv::operator[]: rank = number of c-runs before k; 0 -> 0, else the
+    // (rank-1)-th STORED (non-zero) threshold of the letter (thresholds_ds.hpp:484-488)
+    uint64_t rank = i - li.qbeg;
+    uint64_t thr = 0;
+    if (rank > 0) {
+        uint64_t base = nzpos[li.qbeg];
+        uint64_t cnt = (li.qend < r ? nzpos[li.qend] : nz_total) - base;
+        if (rank - 1 >= cnt) {
+            atomicAdd(err, 1ull);  // select past the last stored threshold: undefined upstream
+        } else {
+            thr = T[base + rank - 1];
+            if (thr > n) atomicAdd(err, 1ull);
+        }
+    }
+    uint64_t d0 = ds ? ds[k] : 0, d1 = de ? de[k] : 0;
+    if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
+    rows[k] = pack_row(S[k], c, lens[k], (uint32_t)dst, lf - S[dst], thr, (uint32_t)d0, (uint32_t)d1);
+}
+
+__global__ void k_sentinel_rows(Row* rows, uint64_t r, uint64_t n) {
+    int t = threadIdx.x;
+    if (t < ROW_PAD) rows[r + t] = pack_row(n, 0, MASK40, (uint32_t)r, 0, 0, 0, 0);
+}
+
+// block count table: cnt[lid][b] = directory offset of the first c-run with index >= b << s
+__global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const LetterInfo* letters,
+                           uint64_t r, uint32_t bshift, uint32_t nblk, uint32_t* cnt) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= r) return;
+    LetterInfo li = letters[Hs[i]];
+    uint32_t* row = cnt + (uint64_t)li.lid * nblk;
+    int64_t b = Qall[i] >> bshift;
+    int64_t pb = i > li.qbeg ? (int64_t)(Qall[i - 1] >> bshift) : -1;
+    for (int64_t x = pb + 1; x <= b; ++x) row[x] = (uint32_t)i;
+    if (i + 1 == li.qend)
+        for (int64_t x = b + 1; x < (int64_t)nblk; ++x) row[x] = li.qend;
+}
+
+__global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < r) q_alloc[i + 1] = Qall[i];
+    if (i == 0) q_alloc[0] = 0;
+    if (i < Q_PAD) q_alloc[r + 1 + i] = 0xffffffffu;
+}
+
+__global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, uint64_t r, SamplePair* out) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < r) out[i] = SamplePair{ssa[i], esa[i]};
+}
+
+}  // namespace
+
+int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
+                      const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
+                      const uint64_t* d_ds, const uint64_t* d_de) {
+    const uint64_t r = ix->r;
+    if (r == 0 || r > 0xfffffff0ull) {
+        set_error("number of runs %llu out of range (1 .. 2^32-16)", (unsigned long long)r);
+        return SPX_E_FORMAT;
+    }
+    hipStream_t st = nullptr;
+    DevBuf H, iota, Hs, Qall, S, ls, LFs, flag, nzpos, T, tmp, err;
+    SPX_HIP(H.alloc(r));
+    SPX_HIP(iota.alloc(r * 4));
+    SPX_HIP(Hs.alloc(r));
+    SPX_HIP(Qall.alloc(r * 4));
+    SPX_HIP(S.alloc((r + 1) * 8));
+    SPX_HIP(err.alloc(8));
+    SPX_HIP(hipMemsetAsync(err.p, 0, 8, st));
+
+    k_norm_heads<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, r, H.as<uint8_t>(),
+                                              iota.as<uint32_t>(), err.as<unsigned long long>());
+    // S = exclusive scan of run lengths; n = S[r]
+    size_t tb = 0, tb2 = 0;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_lens, S.as<uint64_t>(), r, st));
+    SPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, H.as<uint8_t>(), Hs.as<uint8_t>(),
+                                               iota.as<uint32_t>(), Qall.as<uint32_t>(), r, 0, 8, st));
+    if (tb2 > tb) tb = tb2;
+    SPX_HIP(tmp.alloc(tb + 256));
+    size_t tbs = tb;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, d_lens, S.as<uint64_t>(), r, st));
+    uint64_t last_s = 0, last_len = 0;
+    SPX_HIP(hipMemcpyAsync(&last_s, S.as<uint64_t>() + (r - 1), 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&last_len, d_lens + (r - 1), 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    const uint64_t n = last_s + last_len;
+    if (n > MASK40 - 2) {
+        set_error("BWT length %llu exceeds the 40-bit position field", (unsigned long long)n);
+        return SPX_E_FORMAT;
+    }
+    ix->n = n;
+    SPX_HIP(hipMemcpyAsync(S.as<uint64_t>() + r, &n, 8, hipMemcpyHostToDevice, st));
+
+    // runs grouped by head letter, run order kept: the per-letter directories Q_c
+    tbs = tb;
+    SPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbs, H.as<uint8_t>(), Hs.as<uint8_t>(),
+                                               iota.as<uint32_t>(), Qall.as<uint32_t>(), r, 0, 8, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    (void)hipFree(iota.p);
+    iota.p = nullptr;
+    (void)hipFree(H.p);
+    H.p = nullptr;
+
+    // LF image of every run start = exclusive scan of lengths in (letter, run) order
+    SPX_HIP(ls.alloc(r * 8));
+    SPX_HIP(LFs.alloc((r + 1) * 8));
+    k_gather_u64<<<nblocks(r), TPB, 0, st>>>(d_lens, Qall.as<uint32_t>(), r, ls.as<uint64_t>());
+    tbs = tb;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, ls.as<uint64_t>(), LFs.as<uint64_t>(), r, st));
+    SPX_HIP(hipMemcpyAsync(LFs.as<uint64_t>() + r, &n, 8, hipMemcpyHostToDevice, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    (void)hipFree(ls.p);
+    ls.p = nullptr;
+
+    // stored (non-zero) thresholds per letter
+    SPX_HIP(flag.alloc(r * 4));
+    SPX_HIP(nzpos.alloc((r + 1) * 4));
+    k_nonzero_flag<<<nblocks(r), TPB, 0, st>>>(d_thr, Qall.as<uint32_t>(), r, flag.as<uint32_t>());
+    size_t tb3 = 0;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, flag.as<uint32_t>(), nzpos.as<uint32_t>(), r, st));
+    if (tb3 > tb) {
+        set_error("scan scratch mis-sized");
+        return SPX_E_HIP;
+    }
+    tbs = tb;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, flag.as<uint32_t>(), nzpos.as<uint32_t>(), r, st));
+    uint32_t last_pos = 0, last_flag = 0;
+    SPX_HIP(hipMemcpyAsync(&last_pos, nzpos.as<uint32_t>() + (r - 1), 4, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&last_flag, flag.as<uint32_t>() + (r - 1), 4, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    const uint64_t nz_total = (uint64_t)last_pos + last_flag;
+    (void)hipFree(flag.p);
+    flag.p = nullptr;
+    SPX_HIP(T.alloc((nz_total + 1) * 8));
+    k_compact_thr<<<nblocks(r), TPB, 0, st>>>(d_thr, Qall.as<uint32_t>(), nzpos.as<uint32_t>(), r,
+                                               T.as<uint64_t>());
+
+    // letters
+    SPX_HIP(hipMalloc((void**)&ix->letters, 256 * sizeof(LetterInfo)));
+    k_letters<<<1, 256, 0, st>>>(Hs.as<uint8_t>(), LFs.as<uint64_t>(), S.as<uint64_t>(), r, n,
+                                  ix->letters);
+    std::vector<LetterInfo> hl(256);
+    SPX_HIP(hipMemcpyAsync(hl.data(), ix->letters, 256 * sizeof(LetterInfo), hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    uint32_t nletters = 0;
+    for (auto& li : hl)
+        if (li.lid != NO_LETTER) nletters++;
+
+    // rows
+    SPX_HIP(hipMalloc((void**)&ix->rows, (r + ROW_PAD) * sizeof(Row)));
+    k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
+                                              S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
+                                              T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters, r,
+                                              n, ix->rows, err.as<unsigned long long>());
+    k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, n);
+
+    // directory block size: about 4 runs of a typical letter per block
+    uint32_t bshift = 2;
+    while ((1u << bshift) < 4 * nletters && bshift < 16) bshift++;
+    const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
+    SPX_HIP(hipMalloc((void**)&ix->cnt, (uint64_t)nletters * nblk * 4 + 64));
+    k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, bshift,
+                                            nblk, ix->cnt);
+    SPX_HIP(hipMalloc((void**)&ix->q_alloc, (r + 1 + Q_PAD) * 4));
+    k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
+                                                                         ix->q_alloc);
+    uint64_t bytes = (r + ROW_PAD) * sizeof(Row) + (uint64_t)nletters * nblk * 4 + (r + 1 + Q_PAD) * 4 +
+                     256 * sizeof(LetterInfo);
+    if (d_ssa && d_esa) {
+        SPX_HIP(hipMalloc((void**)&ix->samples, r * sizeof(SamplePair)));
+        k_samples<<<nblocks(r), TPB, 0, st>>>(d_ssa, d_esa, r, ix->samples);
+        bytes += r * sizeof(SamplePair);
+        ix->has_samples = true;
+    }
+    ix->has_docs = d_ds && d_de;
+
+    // scalars of the initial state (compute_ms_pml.cpp:243, 298, 575, 641-642)
+    Row last_row, first_row;
+    SamplePair last_sp{0, 0};
+    SPX_HIP(hipMemcpyAsync(&last_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&first_row, ix->rows, sizeof(Row), hipMemcpyDeviceToHost, st));
+    if (ix->samples)
+        SPX_HIP(hipMemcpyAsync(&last_sp, ix->samples + (r - 1), sizeof(SamplePair), hipMemcpyDeviceToHost, st));
+    unsigned long long herr = 0;
+    SPX_HIP(hipMemcpyAsync(&herr, err.p, 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    if (herr) {
+        set_error("index arrays violate a structural invariant (%llu violations: zero/oversized run "
+                  "length, threshold select past the stored thresholds, threshold > n, or doc id > 65535)",
+                  herr);
+        return SPX_E_FORMAT;
+    }
+
+    DevIndex& v = ix->view;
+    v.rows = ix->rows;
+    v.cnt = ix->cnt;
+    v.Q = ix->q_alloc + 1;
+    v.samples = ix->samples;
+    v.letters = ix->letters;
+    v.text = nullptr;
+    v.n_text = 0;
+    v.n = n;
+    v.r = (uint32_t)r;
+    v.nblk = nblk;
+    v.bshift = bshift;
+    v.init_k = (uint32_t)(r - 1);
+    v.init_off = row_len(last_row) - 1;
+    v.init_sample = ix->samples ? (last_sp.se + 1) % n : 0;
+    v.init_doc = row_docE(last_row);
+    v.doc_at0 = row_docS(first_row);
+    ix->device_bytes = bytes;
+    return SPX_OK;
+}
+
+}  // namespace spx

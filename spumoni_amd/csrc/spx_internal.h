@@ -1,0 +1,81 @@
+// spx_internal.h -- private definitions shared by the library's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/spumoni_gpu.h"
+#include "spx_layout.h"
+
+namespace spx {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SPX_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return spx::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// counters written by the walk kernels (one instance per index, device memory)
+struct WalkCounters {
+    unsigned long long next_read;  // dynamic work queue head
+    unsigned long long steps;
+    unsigned long long jumps;
+    unsigned long long pred_jumps;
+    unsigned long long row_loads;
+    unsigned long long dir_loads;
+    unsigned long long error;      // non-zero: a structural invariant was violated
+    unsigned long long pad_;
+};
+
+struct BatchArgs {
+    const uint8_t* seqs;
+    const uint64_t* offs;
+    uint64_t nreads;
+    uint32_t* out_lengths;
+    uint64_t* out_pointers;
+    uint32_t* out_docs;
+    spx_class* out_class;
+    uint64_t bin_width;
+    uint64_t max_value_thr;
+    WalkCounters* counters;
+};
+
+}  // namespace spx
+
+struct spx_index {
+    int device = 0;
+    uint64_t n = 0, r = 0;
+    bool has_samples = false, has_docs = false;
+    spx::Row* rows = nullptr;
+    uint32_t* cnt = nullptr;
+    uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
+    spx::SamplePair* samples = nullptr;
+    spx::LetterInfo* letters = nullptr;
+    uint8_t* text = nullptr;
+    uint64_t n_text = 0;
+    spx::DevIndex view{};
+    spx::WalkCounters* counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+    hipStream_t last_stream = nullptr;
+    uint64_t device_bytes = 0;
+    int variant = 0;      // 0 auto, 1 lane-per-read, 64 wave-per-read
+    int waves_per_cu = 0; // 0 = default occupancy target
+    std::mutex mu;
+};
+
+namespace spx {
+// spx_flatten.hip: builds every device array of `ix` from raw per-run arrays
+// that already live on the device.
+int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
+                      const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
+                      const uint64_t* d_ds, const uint64_t* d_de);
+// spx_walk.hip
+int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
+                hipStream_t stream);
+int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream);
+}  // namespace spx

@@ -1,0 +1,158 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from spumoni_amd import capi, synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+DNA = list(b"ACGT")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi.lib()
+    return 0
+
+
+def _compare_all(oracle_mod, raw, text, seqs, offs, ix=None):
+    """PML, PML+doc, MS, MS+doc(+lengths) and the classifier, HIP vs oracle."""
+    rawc = raw.cpu()
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    ix = ix or capi.Index.from_raw(raw, 0)
+    has_docs = raw.doc_start is not None
+    # --- PML
+    want = orc.pml(seqs, offs)
+    got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(7, 3))
+    assert np.array_equal(got["lengths"], want)
+    f, a, b, s = oracle_mod.classify(want, offs, 7, 3)
+    assert np.array_equal(got["class"]["above"], a)
+    assert np.array_equal(got["class"]["below"], b)
+    assert np.array_equal(got["class"]["sum_max"], s)
+    if has_docs:
+        wl, wd = orc.pml(seqs, offs, want_docs=True)
+        got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True)
+        assert np.array_equal(got["lengths"], wl)
+        assert np.array_equal(got["docs"], wd)
+    # --- MS
+    if raw.ssa is not None:
+        w = orc.ms(seqs, offs, want_docs=has_docs, text=text)
+        got = ix.query_host(capi.SPX_MODE_MS, seqs, offs, want_lengths=text is not None, want_docs=has_docs,
+                            classify=(5, 4) if text is not None else None)
+        assert np.array_equal(got["pointers"], w["pointers"])
+        if has_docs:
+            assert np.array_equal(got["docs"], w["docs"])
+        if text is not None:
+            assert np.array_equal(got["lengths"], w["lengths"])
+            f, a, b, s = oracle_mod.classify(w["lengths"], offs, 5, 4)
+            assert np.array_equal(got["class"]["above"], a)
+            assert np.array_equal(got["class"]["below"], b)
+            assert np.array_equal(got["class"]["sum_max"], s)
+    st = ix.last_stats()
+    return ix, st
+
+
+@pytest.mark.parametrize(
+    "seed,n,letters,extra",
+    [
+        (1, 300, DNA, [ord("N")]),
+        (2, 2000, DNA + [ord("N")], [ord("Z"), 0, 1, 2]),
+        (3, 5000, [3, 4, 5, 90, 127, 128, 129, 200, 255], [2, 250]),  # promoted alphabet, bytes >= 128
+        (4, 1500, list(range(3, 60)), [1]),
+        (5, 64, [ord("A")], [ord("C")]),
+    ],
+)
+def test_real_bwt_parity(gpu, oracle_mod, seed, n, letters, extra):
+    raw, text = cases.real_case(seed, n, letters)
+    rng = np.random.default_rng(1000 + seed)
+    seqs, offs = cases.reads_mixed(rng, text, letters, 300, 120, extra)
+    _compare_all(oracle_mod, raw, text, seqs, offs)
+
+
+def test_single_read_and_empty_batch(gpu, oracle_mod):
+    raw, text = cases.real_case(11, 500, DNA)
+    ix = capi.Index.from_raw(raw, 0)
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    rd = text[10:90].copy()
+    offs = np.array([0, rd.size])
+    assert np.array_equal(ix.query_host(capi.SPX_MODE_PML, rd, offs)["lengths"], orc.pml(rd, offs))
+    # empty batch / all-empty reads
+    out = ix.query_host(capi.SPX_MODE_PML, np.zeros(0, np.uint8), np.array([0]))
+    assert out["lengths"].size == 0
+    out = ix.query_host(capi.SPX_MODE_PML, np.zeros(0, np.uint8), np.array([0, 0, 0]), classify=(150, 3))
+    assert out["lengths"].size == 0 and out["class"].size == 2
+
+
+@pytest.mark.parametrize("sigma,mean_run,zipf,r", [(4, 6.0, 0.0, 20000), (253, 3.0, 1.0, 50000), (16, 1.0, 0.0, 3000)])
+def test_statistical_rlbwt_parity(gpu, oracle_mod, sigma, mean_run, zipf, r):
+    letters = DNA if sigma == 4 else None
+    raw = synth.statistical_rlbwt(r, sigma, mean_run, seed=sigma, device="cuda", zipf=zipf, letters=letters,
+                                  with_samples=True, n_docs=10)
+    seqs, offs = synth.simulate_reads(raw, 4000, 60, seed=3, positive_fraction=0.5, f_mis=0.05)
+    _, st = _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy())
+    assert st["steps"] == 4000 * 60
+
+
+def test_device_resident_query_matches_host_query(gpu, oracle_mod):
+    raw = synth.statistical_rlbwt(30000, 253, 4.0, seed=9, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 5000, 44, seed=4)
+    ix = capi.Index.from_raw(raw, 0)
+    d_seqs = capi.pad_seqs(seqs)
+    d_len = torch.empty(seqs.numel(), dtype=torch.int32, device="cuda")
+    d_cls = torch.empty((offs.numel() - 1, 2), dtype=torch.int64, device="cuda")
+    ix.query_device(capi.SPX_MODE_PML, d_seqs, offs, seqs.numel(), d_lengths=d_len, d_class=d_cls, bin_width=150,
+                    max_value_thr=5)
+    torch.cuda.synchronize()
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs.cpu().numpy(), offs.cpu().numpy())
+    assert np.array_equal(d_len.cpu().numpy().view(np.uint32), want)
+    st = ix.last_stats()
+    ost = orc.stats(seqs.cpu().numpy(), offs.cpu().numpy())
+    assert (st["steps"], st["jumps"], st["pred_jumps"]) == (ost["steps"], ost["jumps"], ost["pred_jumps"])
+    assert st["kernel_ms"] > 0
+
+
+def test_raw_file_loader(gpu, oracle_mod, tmp_path):
+    raw, text = cases.real_case(21, 3000, DNA)
+    prefix = str(tmp_path / "idx")
+    raw.write_raw_files(prefix)
+    rng = np.random.default_rng(5)
+    seqs, offs = cases.reads_mixed(rng, text, DNA, 100, 100)
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    for mode in (capi.SPX_MODE_PML, capi.SPX_MODE_MS):
+        ix = capi.Index.load_raw(prefix, mode, 0)
+        assert (ix.n, ix.r) == (raw.n, raw.r)
+        got = ix.query_host(mode, seqs, offs, want_lengths=(mode == capi.SPX_MODE_PML))
+        if mode == capi.SPX_MODE_PML:
+            assert np.array_equal(got["lengths"], orc.pml(seqs, offs))
+        else:
+            assert np.array_equal(got["pointers"], orc.ms(seqs, offs)["pointers"])
+
+
+def test_invalid_index_is_rejected(gpu):
+    raw, _ = cases.real_case(31, 400, DNA)
+    bad = raw.cpu()
+    bad.lens = bad.lens.clone()
+    bad.lens[3] = 0
+    with pytest.raises(capi.SpxError):
+        capi.Index.from_raw(bad, 0)
+
+
+def test_config1_ecoli_scale(gpu, oracle_mod):
+    """BASELINE config[0] shape: single 4.64 Mbp genome (+revcomp), 150 bp reads, PML -c."""
+    g = synth.random_genome(4_641_652, seed=1)
+    text, doc_lengths = synth.pangenome_text([g])
+    raw = synth.index_from_text(torch.from_numpy(text).cuda(), doc_lengths=doc_lengths, with_samples=False)
+    seqs, offs = synth.sample_reads(text, 20_000, 150, seed=11)
+    ix = capi.Index.from_raw(raw, 0)
+    got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(150, 3 + 4))
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs, offs)
+    assert np.array_equal(got["lengths"], want)
+    f, a, b, s = oracle_mod.classify(want, offs, 150, 7)
+    assert np.array_equal(got["class"]["above"], a)
+    # sampled reads are FOUND, reversed (null) reads are not: the classifier separates them
+    assert 0.3 < f.mean() < 0.7

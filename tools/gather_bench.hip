@@ -1,0 +1,104 @@
+// gather_bench.hip -- measures the ceiling the walk kernel lives under: dependent
+// random gathers of B bytes per lane from a table much larger than the 256 MiB
+// Infinity Cache.  Each lane runs one chain: the next row index is a hash of the
+// row just loaded (so the load cannot be hoisted), exactly like the backward search.
+// Prints rows/s and GB/s of useful bytes for B in {16,32,64} and several occupancies.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                     \
+    do {                                                                          \
+        hipError_t e = (x);                                                       \
+        if (e != hipSuccess) {                                                    \
+            printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__);       \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+template <int B>
+__global__ void __launch_bounds__(256) k_chase(const uint4* __restrict__ tab, uint64_t nrows, int iters,
+                                               uint64_t* sink) {
+    uint64_t idx = mix(blockIdx.x * 256ull + threadIdx.x + 1) % nrows;
+    uint64_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint4* p = tab + idx * (B / 16);
+        uint4 v = p[0];
+        uint64_t h = v.x ^ ((uint64_t)v.y << 32);
+        if (B >= 32) {
+            uint4 w = p[1];
+            h ^= w.z;
+        }
+        if (B >= 64) {
+            uint4 w = p[2];
+            uint4 z = p[3];
+            h ^= w.x ^ z.w;
+        }
+        acc += h;
+        idx = mix(h + idx + i) % nrows;
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+__global__ void k_fill(uint4* tab, uint64_t n16) {
+    uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i < n16) {
+        uint64_t h = mix(i + 7);
+        tab[i] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)(h * 3), (uint32_t)(h * 7));
+    }
+}
+
+template <int B>
+void run(const uint4* tab, uint64_t bytes, uint64_t* sink, int blocks_per_cu, int ncu) {
+    const uint64_t nrows = bytes / B;
+    const int iters = 2000;
+    const int grid = blocks_per_cu * ncu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    k_chase<B><<<grid, 256>>>(tab, nrows, 100, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    k_chase<B><<<grid, 256>>>(tab, nrows, iters, sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double loads = (double)grid * 256 * iters;
+    printf("B=%3d blocks/CU=%d (waves/CU=%2d) lanes=%8.0f : %8.2f Grows/s  %8.1f GB/s useful  %8.1f GB/s @64B-sector  latency/iter %.0f ns\n",
+           B, blocks_per_cu, blocks_per_cu * 4, (double)grid * 256, loads / ms / 1e6, loads * B / ms / 1e6,
+           loads * (B < 64 ? 64 : B) / ms / 1e6, ms * 1e6 / iters);
+}
+
+int main(int argc, char** argv) {
+    uint64_t gb = argc > 1 ? atoll(argv[1]) : 16;
+    uint64_t bytes = gb << 30;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs, %.1f GB, table %llu GB\n", prop.gcnArchName, prop.multiProcessorCount,
+           prop.totalGlobalMem / 1e9, (unsigned long long)gb);
+    uint4* tab;
+    uint64_t* sink;
+    CK(hipMalloc(&tab, bytes));
+    CK(hipMalloc(&sink, 8));
+    k_fill<<<(unsigned)((bytes / 16 + 255) / 256), 256>>>(tab, bytes / 16);
+    CK(hipDeviceSynchronize());
+    const int ncu = prop.multiProcessorCount;
+    for (int bpc : {1, 2, 4, 8}) {
+        run<16>(tab, bytes, sink, bpc, ncu);
+        run<32>(tab, bytes, sink, bpc, ncu);
+        run<64>(tab, bytes, sink, bpc, ncu);
+    }
+    return 0;
+}
