@@ -230,10 +230,11 @@ class Index:
 
 
 def pad_seqs(seqs):
-    """Return a device/host tensor copy of seqs padded to a multiple of 8 (+8) bytes."""
+    """Return a copy of seqs with the slack spx_query_batch_device asks for
+    (readable for round_up(n, 4) + 32 bytes)."""
     import torch
 
     n = seqs.numel()
-    padded = torch.zeros(((n + 7) // 8) * 8 + 8, dtype=torch.uint8, device=seqs.device)
+    padded = torch.zeros(((n + 3) // 4) * 4 + 32, dtype=torch.uint8, device=seqs.device)
     padded[:n] = seqs
     return padded

@@ -102,6 +102,8 @@ void spx_index_free(spx_index* ix) {
     if (ix->cnt) (void)hipFree(ix->cnt);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);
     if (ix->samples) (void)hipFree(ix->samples);
+    if (ix->dirrows) (void)hipFree(ix->dirrows);
+    if (ix->ss_by_run) (void)hipFree(ix->ss_by_run);
     if (ix->letters) (void)hipFree(ix->letters);
     if (ix->text) (void)hipFree(ix->text);
     if (ix->counters) (void)hipFree(ix->counters);
@@ -322,8 +324,8 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs,
                          d_out_class, bin_width);
     if (rc != SPX_OK) return rc;
-    if (((uintptr_t)d_seqs & 7) != 0) {
-        set_error("d_seqs must be 8-byte aligned (and readable up to the next multiple of 8)");
+    if (((uintptr_t)d_seqs & 15) != 0) {
+        set_error("d_seqs must be 16-byte aligned (and readable for round_up(total_chars, 4) + 32 bytes)");
         return SPX_E_ARG;
     }
     std::lock_guard<std::mutex> g(ix->mu);
@@ -334,6 +336,7 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     a.seqs = d_seqs;
     a.offs = d_offsets;
     a.nreads = nreads;
+    a.total_chars = total_chars;
     a.out_lengths = d_out_lengths;
     a.out_pointers = d_out_pointers;
     a.out_docs = d_out_docs;
@@ -372,7 +375,7 @@ int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t
             if (p) (void)hipFree(p);
         }
     } dseq, doff, dlen, dptr, ddoc, dcls;
-    const uint64_t padded = ((total + 7) / 8) * 8 + 8;
+    const uint64_t padded = ((total + 3) / 4) * 4 + 32;
     SPX_HIP(hipMalloc(&dseq.p, padded));
     SPX_HIP(hipMemset(dseq.p, 0, padded));
     SPX_HIP(hipMemcpy(dseq.p, seqs, total, hipMemcpyHostToDevice));

@@ -119,7 +119,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
                              const uint64_t* S, const uint64_t* lens, const uint32_t* nzpos,
                              const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
                              const uint64_t* de, const LetterInfo* letters, uint64_t r, uint64_t n,
-                             Row* rows, unsigned long long* err) {
+                             Row* rows, DirRow* dirrows, unsigned long long* err) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
     uint32_t k = Qall[i];
@@ -145,6 +145,27 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
     uint64_t d0 = ds ? ds[k] : 0, d1 = de ? de[k] : 0;
     if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
     rows[k] = pack_row(S[k], c, lens[k], (uint32_t)dst, lf - S[dst], thr, (uint32_t)d0, (uint32_t)d1);
+    // directory row i: successor landing = LF(S[k]); predecessor landing = that position - 1
+    // (= LF of the last character of the previous run in directory order)
+    const uint64_t soff = lf - S[dst];
+    uint64_t prun = 0, poff = 0, dprev = 0;
+    if (i > 0) {
+        if (soff > 0) {
+            prun = dst;
+            poff = soff - 1;
+        } else {
+            prun = dst - 1;  // lf > 0 here, so dst >= 1
+            poff = S[dst] - S[dst - 1] - 1;
+        }
+        dprev = de ? de[Qall[i - 1]] : 0;
+    }
+    dirrows[i] = pack_dirrow(k, thr, (uint32_t)dst, soff, (uint32_t)prun, poff, (uint32_t)d0, (uint32_t)dprev);
+    if (i + 1 == r) {  // sentinel directory row r: LF image n, predecessor = position n-1
+        const uint64_t dlast = de ? de[k] : 0;
+        DirRow sd = pack_dirrow((uint32_t)r, 0, (uint32_t)r, 0, (uint32_t)(r - 1), S[r] - S[r - 1] - 1, 0,
+                                (uint32_t)dlast);
+        for (int t = 0; t < 4; ++t) dirrows[r + t] = sd;
+    }
 }
 
 __global__ void k_sentinel_rows(Row* rows, uint64_t r, uint64_t n) {
@@ -173,9 +194,21 @@ __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
     if (i < Q_PAD) q_alloc[r + 1 + i] = 0xffffffffu;
 }
 
-__global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, uint64_t r, SamplePair* out) {
+// MS samples in directory order: entry i = {samples_start[Q[i]], samples_last[Q[i-1]]};
+// plus samples_start by run index for the "byte >= 128 sitting on its own run" case
+__global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, const uint32_t* Qall, uint64_t r,
+                          SamplePair* out, uint64_t* ss_by_run) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
-    if (i < r) out[i] = SamplePair{ssa[i], esa[i]};
+    if (i > r) return;
+    SamplePair sp;
+    sp.ss = i < r ? ssa[Qall[i]] : 0;
+    sp.se = i > 0 ? esa[Qall[i - 1]] : 0;
+    out[i] = sp;
+    if (i < r) ss_by_run[i] = ssa[i];
+    if (i == r) {
+        ss_by_run[r] = 0;
+        ss_by_run[r + 1] = 0;
+    }
 }
 
 }  // namespace
@@ -278,15 +311,17 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 
     // rows
     SPX_HIP(hipMalloc((void**)&ix->rows, (r + ROW_PAD) * sizeof(Row)));
+    SPX_HIP(hipMalloc((void**)&ix->dirrows, (r + ROW_PAD) * sizeof(DirRow)));
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters, r,
-                                              n, ix->rows, err.as<unsigned long long>());
+                                              n, ix->rows, ix->dirrows, err.as<unsigned long long>());
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, n);
 
-    // directory block size: about 4 runs of a typical letter per block
+    // directory block size: about half a run of a typical letter per block, so that most
+    // blocks hold no run of the wanted letter and the walk can skip the Q window
     uint32_t bshift = 2;
-    while ((1u << bshift) < 4 * nletters && bshift < 16) bshift++;
+    while ((2u << bshift) <= nletters && bshift < 16) bshift++;
     const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
     SPX_HIP(hipMalloc((void**)&ix->cnt, (uint64_t)nletters * nblk * 4 + 64));
     k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, bshift,
@@ -294,23 +329,24 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     SPX_HIP(hipMalloc((void**)&ix->q_alloc, (r + 1 + Q_PAD) * 4));
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
-    uint64_t bytes = (r + ROW_PAD) * sizeof(Row) + (uint64_t)nletters * nblk * 4 + (r + 1 + Q_PAD) * 4 +
-                     256 * sizeof(LetterInfo);
+    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(DirRow)) + (uint64_t)nletters * nblk * 4 +
+                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo);
+    uint64_t last_esa = 0;
     if (d_ssa && d_esa) {
-        SPX_HIP(hipMalloc((void**)&ix->samples, r * sizeof(SamplePair)));
-        k_samples<<<nblocks(r), TPB, 0, st>>>(d_ssa, d_esa, r, ix->samples);
-        bytes += r * sizeof(SamplePair);
+        SPX_HIP(hipMalloc((void**)&ix->samples, (r + 2) * sizeof(SamplePair)));
+        SPX_HIP(hipMalloc((void**)&ix->ss_by_run, (r + 4) * 8));
+        k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, ix->samples,
+                                                   ix->ss_by_run);
+        SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8;
         ix->has_samples = true;
     }
     ix->has_docs = d_ds && d_de;
 
     // scalars of the initial state (compute_ms_pml.cpp:243, 298, 575, 641-642)
     Row last_row, first_row;
-    SamplePair last_sp{0, 0};
     SPX_HIP(hipMemcpyAsync(&last_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost, st));
     SPX_HIP(hipMemcpyAsync(&first_row, ix->rows, sizeof(Row), hipMemcpyDeviceToHost, st));
-    if (ix->samples)
-        SPX_HIP(hipMemcpyAsync(&last_sp, ix->samples + (r - 1), sizeof(SamplePair), hipMemcpyDeviceToHost, st));
     unsigned long long herr = 0;
     SPX_HIP(hipMemcpyAsync(&herr, err.p, 8, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipStreamSynchronize(st));
@@ -323,6 +359,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 
     DevIndex& v = ix->view;
     v.rows = ix->rows;
+    v.dirrows = ix->dirrows;
+    v.ss_by_run = ix->ss_by_run;
     v.cnt = ix->cnt;
     v.Q = ix->q_alloc + 1;
     v.samples = ix->samples;
@@ -335,7 +373,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.bshift = bshift;
     v.init_k = (uint32_t)(r - 1);
     v.init_off = row_len(last_row) - 1;
-    v.init_sample = ix->samples ? (last_sp.se + 1) % n : 0;
+    v.init_sample = ix->samples ? (last_esa + 1) % n : 0;
     v.init_doc = row_docE(last_row);
     v.doc_at0 = row_docS(first_row);
     ix->device_bytes = bytes;

@@ -21,7 +21,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // counters written by the walk kernels (one instance per index, device memory)
 struct WalkCounters {
-    unsigned long long next_read;  // dynamic work queue head
+    unsigned long long reserved0;
     unsigned long long steps;
     unsigned long long jumps;
     unsigned long long pred_jumps;
@@ -32,9 +32,10 @@ struct WalkCounters {
 };
 
 struct BatchArgs {
-    const uint8_t* seqs;
+    const uint8_t* seqs;   // readable for round_up(total_chars, 4) + 32 bytes
     const uint64_t* offs;
     uint64_t nreads;
+    uint64_t total_chars;
     uint32_t* out_lengths;
     uint64_t* out_pointers;
     uint32_t* out_docs;
@@ -53,7 +54,9 @@ struct spx_index {
     spx::Row* rows = nullptr;
     uint32_t* cnt = nullptr;
     uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
+    spx::DirRow* dirrows = nullptr;
     spx::SamplePair* samples = nullptr;
+    uint64_t* ss_by_run = nullptr;
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;
     uint64_t n_text = 0;

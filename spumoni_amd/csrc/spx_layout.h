@@ -63,6 +63,45 @@ SPX_HD uint64_t row_LFoff(const Row& r) { return r.q2 & MASK40; }
 SPX_HD uint32_t row_docE(const Row& r) { return (uint32_t)(r.q2 >> 48); }
 SPX_HD uint64_t row_THR(const Row& r) { return r.q3 & MASK40; }
 
+// Directory row i (i = position in the (letter, run index) order; Q[i] is the run):
+// everything a threshold jump needs, for BOTH outcomes, in one 32-byte gather:
+//   q        run index Q[i]                 (successor c-run of the walk's position)
+//   THR      thresholds[q]
+//   sLF*     where LF(start of q) lands     (taken when pos >= THR: jump to successor)
+//   pLF*     where LF(start of q) - 1 lands (= LF of the LAST character of run Q[i-1]:
+//            taken when pos < THR: jump to predecessor; LF images of consecutive
+//            directory rows are adjacent, also across letter boundaries)
+//   docS     start_runs_doc[q];  docEp = end_runs_doc[Q[i-1]]
+// Row i = r is a sentinel: no successor, predecessor = last run in directory order.
+struct alignas(32) DirRow {
+    uint64_t d0;  // q[32] | docS[16] << 32 | docEp[16] << 48
+    uint64_t d1;  // THR[40] | sLFrun[0:24] << 40
+    uint64_t d2;  // sLFoff[40] | sLFrun[24:32] << 40 | pLFrun[0:16] << 48
+    uint64_t d3;  // pLFoff[40] | pLFrun[16:32] << 40
+};
+
+SPX_HD DirRow pack_dirrow(uint32_t q, uint64_t THR, uint32_t sLFrun, uint64_t sLFoff,
+                          uint32_t pLFrun, uint64_t pLFoff, uint32_t docS, uint32_t docEp) {
+    DirRow d;
+    d.d0 = (uint64_t)q | ((uint64_t)(docS & 0xffff) << 32) | ((uint64_t)(docEp & 0xffff) << 48);
+    d.d1 = (THR & MASK40) | ((uint64_t)(sLFrun & 0xffffff) << 40);
+    d.d2 = (sLFoff & MASK40) | ((uint64_t)(sLFrun >> 24) << 40) | ((uint64_t)(pLFrun & 0xffff) << 48);
+    d.d3 = (pLFoff & MASK40) | ((uint64_t)(pLFrun >> 16) << 40);
+    return d;
+}
+SPX_HD uint32_t dir_q(const DirRow& d) { return (uint32_t)d.d0; }
+SPX_HD uint32_t dir_docS(const DirRow& d) { return (uint32_t)(d.d0 >> 32) & 0xffff; }
+SPX_HD uint32_t dir_docEp(const DirRow& d) { return (uint32_t)(d.d0 >> 48); }
+SPX_HD uint64_t dir_THR(const DirRow& d) { return d.d1 & MASK40; }
+SPX_HD uint32_t dir_sLFrun(const DirRow& d) {
+    return (uint32_t)(d.d1 >> 40) | ((uint32_t)((d.d2 >> 40) & 0xff) << 24);
+}
+SPX_HD uint64_t dir_sLFoff(const DirRow& d) { return d.d2 & MASK40; }
+SPX_HD uint32_t dir_pLFrun(const DirRow& d) {
+    return (uint32_t)(d.d2 >> 48) | ((uint32_t)((d.d3 >> 40) & 0xffff) << 16);
+}
+SPX_HD uint64_t dir_pLFoff(const DirRow& d) { return d.d3 & MASK40; }
+
 // per byte value c: everything the walk needs that depends only on the letter
 struct alignas(16) LetterInfo {
     uint32_t lid;    // dense letter id, NO_LETTER if number_of_letter(c) == 0
@@ -73,7 +112,7 @@ struct alignas(16) LetterInfo {
     uint64_t pad_;
 };
 
-struct SamplePair {  // samples_start / samples_last of one run (MS mode)
+struct SamplePair {  // MS mode, directory order: entry i = {samples_start[Q[i]], samples_last[Q[i-1]]}
     uint64_t ss;
     uint64_t se;
 };
@@ -81,9 +120,11 @@ struct SamplePair {  // samples_start / samples_last of one run (MS mode)
 // kernel-visible view of an index (all pointers are device memory)
 struct DevIndex {
     const Row* rows;            // r + ROW_PAD rows; row r is the "pos == n" sentinel
+    const DirRow* dirrows;      // r + 1 (+ pad) directory rows, (letter, run) order
     const uint32_t* cnt;        // [nletters][nblk] directory offsets (absolute into Q)
     const uint32_t* Q;          // directory; Q[-1] and Q[qtotal .. +Q_PAD) are readable
-    const SamplePair* samples;  // r entries or nullptr
+    const SamplePair* samples;  // r + 1 entries in directory order, or nullptr
+    const uint64_t* ss_by_run;  // samples_start by run index (+2 pad) or nullptr
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;

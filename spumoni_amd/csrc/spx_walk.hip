@@ -5,43 +5,51 @@
 // length extension of ms_t::matching_statistics (:800-810); how it is computed
 // is ours (spx_layout.h).
 //
-// k_walk_lanes -- "lane-per-read state machine".  The walk of one read is a
-// chain of dependent 32-byte gathers (1 per matching character, ~4 per
-// threshold jump), so throughput is purely a question of how many chains are in
-// flight.  Every lane owns one read and runs a small state machine whose every
-// iteration issues exactly ONE round of gathers (whatever its read needs next:
-// a landing row, a directory count, a directory window, the successor /
-// predecessor rows) and then consumes it.  All 64 lanes of a wave therefore
-// always have a gather in flight, no lane ever waits for another lane's longer
-// step, and lanes pull new reads from a device-wide queue as they finish.
-// 2048 lanes per CU x 256 CUs = 524k independent chains keep HBM's random-access
-// path saturated (Little: ~8 MB must be in flight).
+// k_walk_lanes -- "lane-per-read state machine".
+// The walk of one read is a chain of dependent 32-byte gathers (1 per matching
+// character, 3-4 per threshold jump), and MI355X's random-gather ceiling is
+// ~50 G L2-line fills/s (tools/gather_bench.hip) reached with >= 64k chains in
+// flight -- far more chains than the 8k wavefronts the chip holds.  So every
+// LANE owns one read and runs a small state machine.  Each loop iteration
+// issues exactly ONE 32-byte gather per lane, from a single load site, at the
+// address the lane's current phase asks for:
 //
-// k_walk_wave -- "wavefront-per-read"  for batches with too few
-// reads to fill the lanes (long-read workloads): see below.
+//   P_READ   offsets[rd], offsets[rd+1]         (next read of this lane)
+//   P_CHARS  32 characters of the read          (refill, every <= 32 steps)
+//   P_LAND   rows[k0]                           (run the LF step lands in)
+//   P_CNT    cnt[letter][k >> bshift]           (directory block bounds)
+//   P_QS     Q[lo-1 .. lo+6]                    (only if the block holds c-runs)
+//   P_DIR    dirrows[j]                         (threshold + both jump landings)
+//
+// then consumes it and moves to the next phase.  Because the load site is
+// unique, all 64 lanes of a wave always have their gather in flight together
+// no matter which phase each is in: no lane waits for another lane's longer
+// step, and no phase serialises behind another phase's s_waitcnt.
 #include "spx_internal.h"
 
 namespace spx {
 
 namespace {
 
-enum : uint32_t { PH_NEW = 0, PH_LAND = 1, PH_CNT = 2, PH_QS = 3, PH_ROWS = 4, PH_SAMP = 5 };
+enum : uint32_t {
+    P_READ = 0,
+    P_CHARS = 1,
+    P_LAND = 2,
+    P_CNT = 3,
+    P_QS = 4,
+    P_DIR = 5,
+    P_SAMP = 6,
+    P_DONE = 7
+};
 
 constexpr int WALK_TPB = 256;
 
-struct __attribute__((packed, aligned(4))) QWin {
-    uint32_t e[8];
+struct __attribute__((packed, aligned(4))) V16 {  // 16 bytes at 4-byte alignment
+    uint32_t x, y, z, w;
 };
 
-__device__ __forceinline__ Row load_row(const Row* p) {
-    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
-    ulonglong2 a = q[0], b = q[1];
-    Row r;
-    r.q0 = a.x;
-    r.q1 = a.y;
-    r.q2 = b.x;
-    r.q3 = b.y;
-    return r;
+__device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) {
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // ---------------------------------------------------------------------------
@@ -53,14 +61,19 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     for (int t = threadIdx.x; t < 256; t += WALK_TPB) s_let[t] = ix.letters[t];
     __syncthreads();
 
-    const Row* __restrict__ rows = ix.rows;
-    const uint32_t* __restrict__ Q = ix.Q;
-    const uint64_t* __restrict__ seqs64 = reinterpret_cast<const uint64_t*>(b.seqs);
+    const char* const rows_b = reinterpret_cast<const char*>(ix.rows);
+    const char* const dir_b = reinterpret_cast<const char*>(ix.dirrows);
+    const char* const cnt_b = reinterpret_cast<const char*>(ix.cnt);
+    const char* const q_b = reinterpret_cast<const char*>(ix.Q);
+    const char* const seq_b = reinterpret_cast<const char*>(b.seqs);
+    const char* const off_b = reinterpret_cast<const char*>(b.offs);
     const uint32_t R = ix.r;
     const bool want_class = (MODE == SPX_MODE_PML) && b.out_class != nullptr;
+    const uint64_t nlanes = (uint64_t)gridDim.x * WALK_TPB;
 
-    uint32_t ph = PH_NEW;
-    uint64_t rd = 0, base = 0;
+    uint32_t ph = P_READ;
+    uint64_t rd = (uint64_t)blockIdx.x * WALK_TPB + threadIdx.x;
+    uint64_t base = 0;
     uint32_t m = 0, x = 0;  // x = characters still to search; next one is index x-1
     // landed position: run k, offset off; fields of row k
     uint32_t k = 0, H_k = 0, LFrun_k = 0, docs_k = 0;
@@ -72,167 +85,193 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t length = 0, doc = 0;
     uint64_t sample = 0;
     // jump bookkeeping
-    uint32_t c = 0, lo = 0, hi = 0, qs = 0, qp = 0, qbeg = 0, qend = 0;
-    bool has_succ = false, has_pred = false, quirk = false;
-    // character window
-    uint64_t cw = 0, cwn = 0, cw_idx = 0;
+    uint32_t c = 0, lo = 0, hi = 0, jdir = 0, qbeg = 0, qend = 0;
+    bool quirk = false;
+    // character window: 32 bytes starting at byte offset wbase of seqs
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, wbase = 0;
+    // output staging (PML): 8 u16 values of the aligned group [obase, obase+8)
+    uint64_t ob_lo = 0, ob_hi = 0;
     // classifier
     uint32_t bin_lo = 0, bin_max = 0, above = 0, below = 0;
     uint64_t sum_max = 0;
     // statistics
     uint32_t n_steps = 0, n_jumps = 0, n_pred = 0, n_rows = 0, n_dir = 0, n_err = 0;
 
-    for (;;) {
-        if (ph == PH_NEW) {
-            rd = atomicAdd(&b.counters->next_read, 1ull);
-            if (rd >= b.nreads) break;
-            base = b.offs[rd];
-            m = (uint32_t)(b.offs[rd + 1] - base);
-            if (m == 0) {
-                if (want_class) b.out_class[rd] = spx_class{0, 0, 0};
-                continue;
-            }
-            x = m;
-            length = 0;
-            sample = ix.init_sample;  // compute_ms_pml.cpp:575
-            doc = ix.init_doc;        // :298 / :634
-            k0 = ix.init_k;           // pos = bwt_size() - 1   (:243 / :574)
-            offp = ix.init_off;
-            const uint64_t g = base + m - 1;
-            cw_idx = g >> 3;
-            cw = seqs64[cw_idx];
-            cwn = seqs64[cw_idx ? cw_idx - 1 : 0];
-            if (want_class) {
-                const uint32_t w = (uint32_t)b.bin_width;
-                const uint32_t nb = m / w > 0 ? m / w : 1;
-                bin_lo = (nb - 1) * w;
-                bin_max = above = below = 0;
-                sum_max = 0;
-            }
-            ph = PH_LAND;
-        }
+    if (rd >= b.nreads) ph = P_DONE;
 
-        // ---- one round of gathers: whatever this lane's read needs next ----
-        Row ra, rb;
-        uint32_t e0 = 0, e1 = 0;
-        QWin win;
-        SamplePair sa{0, 0}, sb{0, 0};
-        if (ph == PH_LAND) {
-            ra = load_row(rows + k0);
-        } else if (ph == PH_CNT) {
-            const uint32_t* p = ix.cnt + (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
-            e0 = p[0];
-            e1 = p[1];
-        } else if (ph == PH_QS) {
+    while (ph != P_DONE) {
+        // ---- the one gather of this iteration -------------------------------
+        const char* p0;
+        const char* p1;
+        if (ph == P_LAND) {
+            p0 = rows_b + (uint64_t)k0 * sizeof(Row);
+            p1 = p0 + 16;
+        } else if (ph == P_DIR) {
+            p0 = dir_b + (uint64_t)jdir * sizeof(DirRow);
+            p1 = p0 + 16;
+        } else if (ph == P_CNT) {
+            p0 = cnt_b + ((uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift)) * 4;
+            p1 = p0;
+        } else if (ph == P_QS) {
             const int64_t at = (int64_t)(hi - lo <= 6 ? lo : lo + ((hi - lo) >> 1)) - 1;
-            win = *reinterpret_cast<const QWin*>(Q + at);
-        } else if (ph == PH_ROWS) {
-            const uint32_t ia = has_succ ? qs : qp;
-            const uint32_t ib = has_pred ? qp : ia;
-            ra = load_row(rows + ia);
-            rb = load_row(rows + ib);
-            if (MODE == SPX_MODE_MS) {
-                sa = ix.samples[ia];
-                sb = ix.samples[ib];
-            }
-        } else {  // PH_SAMP
-            sa = ix.samples[k];
+            p0 = q_b + at * 4;
+            p1 = p0 + 16;
+        } else if (ph == P_CHARS) {
+            p0 = seq_b + wbase;
+            p1 = p0 + 16;
+        } else if (ph == P_READ) {
+            p0 = off_b + rd * 8;
+            p1 = p0;
+        } else {  // P_SAMP
+            p0 = reinterpret_cast<const char*>(ix.ss_by_run + k);
+            p1 = p0;
         }
+        const V16 ga = *reinterpret_cast<const V16*>(p0);
+        const V16 gb = *reinterpret_cast<const V16*>(p1);
+        SamplePair sp{0, 0};
+        if (MODE == SPX_MODE_MS) {
+            // MS: the samples of the directory position travel with the directory row
+            const SamplePair* ps = ix.samples + (ph == P_DIR ? jdir : 0);
+            sp = *ps;
+        }
+        const uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
+        const uint64_t g2 = u64of(gb.x, gb.y), g3 = u64of(gb.z, gb.w);
 
-        // ---- consume ----
+        // ---- consume ---------------------------------------------------------
         bool do_emit = false;  // a character's result is final -> write it and advance
         bool do_step = false;  // landed on a run -> look at the next character
-        if (ph == PH_LAND) {
+        if (ph == P_LAND) {
             n_rows++;
+            Row ra;
+            ra.q0 = g0;
+            ra.q1 = g1;
+            ra.q2 = g2;
+            ra.q3 = g3;
             const uint64_t len = row_len(ra);
             if (offp >= len) {  // LF image lies in a later run: skip this row
                 offp -= len;
                 k0++;
-                continue;
+            } else {
+                k = k0;
+                off = offp;
+                S_k = row_S(ra);
+                H_k = row_H(ra);
+                LFrun_k = row_LFrun(ra);
+                LFoff_k = row_LFoff(ra);
+                THR_k = row_THR(ra);
+                docs_k = row_docS(ra) | (row_docE(ra) << 16);
+                do_step = true;
             }
-            k = k0;
-            off = offp;
-            S_k = row_S(ra);
-            H_k = row_H(ra);
-            LFrun_k = row_LFrun(ra);
-            LFoff_k = row_LFoff(ra);
-            THR_k = row_THR(ra);
-            docs_k = row_docS(ra) | (row_docE(ra) << 16);
-            do_step = true;
-        } else if (ph == PH_CNT) {
+        } else if (ph == P_DIR) {
+            // compute_ms_pml.cpp:253-278 (PML) / :585-615 (MS) on the flat layout
             n_dir++;
-            lo = e0;
-            hi = e1;
-            ph = PH_QS;
-            continue;
-        } else if (ph == PH_QS) {
+            DirRow dr;
+            dr.d0 = g0;
+            dr.d1 = g1;
+            dr.d2 = g2;
+            dr.d3 = g3;
+            const uint64_t pos = S_k + off;  // sentinel row r has S = n, off = 0
+            const bool has_succ = jdir < qend;  // rnk < number_of_letter(c)   (:259)
+            uint64_t thr = ix.n + 1;            // :254
+            if (!quirk) {
+                if (has_succ) {
+                    thr = dir_THR(dr);
+                    length = 0;
+                    sample = sp.ss;        // samples_start[run_of_j]  (:601)
+                    doc = dir_docS(dr);    // start_runs_doc[run_of_j] (:317)
+                    k0 = dir_sLFrun(dr);   // next_pos = j; LF(j, c)
+                    offp = dir_sLFoff(dr);
+                }
+                if (pos < thr) {  // :270  -> select(rnk-1, c): last character of the previous c-run
+                    n_pred++;
+                    if (jdir <= qbeg) n_err++;  // rnk-- below zero: undefined upstream
+                    length = 0;
+                    sample = sp.se;        // samples_last[run_of_j]  (:611)
+                    doc = dir_docEp(dr);   // end_runs_doc[run_of_j]  (:327)
+                    k0 = dir_pLFrun(dr);
+                    offp = dir_pLFoff(dr);
+                }
+            } else {
+                // byte >= 128 equal to the head of its run with pos < thresholds[run]
+                // (Appendix C1; only reachable with inconsistent thresholds): jdir is the
+                // directory position of run k when off == 0, of the next c-run when off > 0
+                n_pred++;
+                length = 0;
+                sample = sp.se;
+                if (off > 0) {  // select(rnk-1, c) = pos - 1, still inside run k
+                    doc = docs_k >> 16;
+                    k0 = LFrun_k;
+                    offp = LFoff_k + off - 1;
+                } else {
+                    if (jdir <= qbeg) n_err++;
+                    doc = dir_docEp(dr);
+                    k0 = dir_pLFrun(dr);
+                    offp = dir_pLFoff(dr);
+                }
+            }
+            do_emit = true;
+        } else if (ph == P_CNT) {
             n_dir++;
+            lo = (uint32_t)g0;
+            hi = (uint32_t)(g0 >> 32);
+            if (hi == lo) {  // no c-run inside the block: the successor is directory entry lo
+                jdir = lo;
+                ph = P_DIR;
+            } else {
+                ph = P_QS;
+            }
+        } else if (ph == P_QS) {
+            n_dir++;
+            const uint32_t e[8] = {(uint32_t)g0, (uint32_t)(g0 >> 32), (uint32_t)g1, (uint32_t)(g1 >> 32),
+                                   (uint32_t)g2, (uint32_t)(g2 >> 32), (uint32_t)g3, (uint32_t)(g3 >> 32)};
             if (hi - lo <= 6) {
-                // window holds Q[lo-1 .. lo+6]; j = number of c-runs with index < k
+                // window holds Q[lo-1 .. lo+6]; j = lo + number of c-runs of the block with index < k
                 uint32_t cntlt = 0;
 #pragma unroll
-                for (int t = 1; t <= 6; ++t) cntlt += ((uint32_t)t <= hi - lo && win.e[t] < k) ? 1u : 0u;
-                const uint32_t j = lo + cntlt;
-                qp = win.e[0];
-                qs = win.e[1];
-#pragma unroll
-                for (int t = 1; t <= 6; ++t) {
-                    if (cntlt == (uint32_t)t) {
-                        qp = win.e[t];
-                        qs = win.e[t + 1];
-                    }
-                }
-                has_succ = j < qend;
-                has_pred = j > qbeg;
-                ph = PH_ROWS;
+                for (int t = 1; t <= 6; ++t) cntlt += ((uint32_t)t <= hi - lo && e[t] < k) ? 1u : 0u;
+                jdir = lo + cntlt;
+                if (quirk && off > 0) jdir++;  // see P_DIR: entry after run k carries samples_last[k]
+                ph = P_DIR;
             } else {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (win.e[1] < k)
+                if (e[1] < k)
                     lo = mid + 1;
                 else
                     hi = mid;
             }
-            continue;
-        } else if (ph == PH_ROWS) {
-            // compute_ms_pml.cpp:253-278 (PML) / :585-615 (MS) on the flat layout
-            const uint64_t pos = S_k + off;  // sentinel row r has S = n, off = 0
-            uint64_t thr = ix.n + 1;         // :254
-            uint32_t nk = k;
-            uint64_t noff = off;
-            const Row* land = &ra;
-            if (has_succ) {  // rnk < number_of_letter(c)  (:259)
-                thr = row_THR(ra);
+        } else if (ph == P_CHARS) {
+            w0 = g0;
+            w1 = g1;
+            w2 = g2;
+            w3 = g3;
+            do_step = true;  // only entered from a landed state
+        } else if (ph == P_READ) {
+            base = g0;
+            m = (uint32_t)(g1 - g0);
+            if (m == 0) {
+                if (want_class) b.out_class[rd] = spx_class{0, 0, 0};
+                rd += nlanes;
+                if (rd >= b.nreads) ph = P_DONE;
+            } else {
+                x = m;
                 length = 0;
-                sample = sa.ss;           // samples_start[run_of_j]  (:601)
-                doc = row_docS(ra);       // start_runs_doc[run_of_j] (:317)
-                if (!quirk) {
-                    nk = qs;              // next_pos = j = start of the next c-run
-                    noff = 0;
+                sample = ix.init_sample;  // compute_ms_pml.cpp:575
+                doc = ix.init_doc;        // :298 / :634
+                k0 = ix.init_k;           // pos = bwt_size() - 1   (:243 / :574)
+                offp = ix.init_off;
+                wbase = ~0ull;            // no characters loaded yet
+                ob_lo = ob_hi = 0;
+                if (want_class) {
+                    const uint32_t w = (uint32_t)b.bin_width;
+                    const uint32_t nb = m / w > 0 ? m / w : 1;
+                    bin_lo = (nb - 1) * w;
+                    bin_max = above = below = 0;
+                    sum_max = 0;
                 }
+                ph = P_LAND;
             }
-            if (pos < thr) {  // :270
-                n_pred++;
-                length = 0;
-                if (quirk && off > 0) {  // select(rnk-1, c) is the previous position of run k
-                    noff = off - 1;
-                    sample = sa.se;
-                    doc = row_docE(ra);
-                } else {
-                    if (!has_pred) n_err++;  // rnk-- below zero: undefined upstream
-                    nk = qp;
-                    noff = row_len(rb) - 1;
-                    sample = sb.se;        // samples_last[run_of_j]  (:611)
-                    doc = row_docE(rb);    // end_runs_doc[run_of_j]  (:327)
-                    land = &rb;
-                }
-            }
-            // pos = next_pos; pos = LF(pos, c)   (:278, :284)
-            k0 = row_LFrun(*land);
-            offp = row_LFoff(*land) + noff;
-            (void)nk;
-            do_emit = true;
-        } else {  // PH_SAMP: byte >= 128 sitting on its own run (Appendix C1), MS mode
-            sample = sa.ss;
+        } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1), MS mode
+            sample = g0;  // samples_start[run of pos]
             k0 = LFrun_k;
             offp = LFoff_k + off;
             do_emit = true;
@@ -241,59 +280,101 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         if (do_step) {
             // next character: auto c = pattern[m - i - 1]   (:247)
             const uint64_t g = base + x - 1;
-            if ((g >> 3) != cw_idx) {
-                cw = cwn;
-                cw_idx = g >> 3;
-                cwn = seqs64[cw_idx ? cw_idx - 1 : 0];
-            }
-            c = (uint32_t)(cw >> ((g & 7) * 8)) & 0xffu;
-            const LetterInfo li = s_let[c];
-            if (li.lid == NO_LETTER) {  // number_of_letter(c) == 0   (:249)
-                length = 0;
-                if (MODE == SPX_MODE_MS) {
-                    sample = 0;                 // :581
-                    if (DOC) doc = ix.doc_at0;  // :641-642
-                }
-                k0 = li.frun;  // LF(pos, c) = F[c] + 0
-                offp = li.foff;
-                do_emit = true;
-            } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
-                length++;
-                sample--;  // :582 (wraps, Appendix C3)
-                k0 = LFrun_k;
-                offp = LFoff_k + off;
-                do_emit = true;
-            } else if (k < R && H_k == c && S_k + off >= THR_k) {
-                // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
-                // branch runs but select(rank(pos,c),c) == pos, and pos >= thr keeps it there
-                n_jumps++;
-                length = 0;
-                doc = docs_k & 0xffff;  // start_runs_doc[run of pos]
-                if (MODE == SPX_MODE_MS) {
-                    ph = PH_SAMP;  // sample = samples_start[run of pos]
-                    continue;
-                }
-                k0 = LFrun_k;
-                offp = LFoff_k + off;
-                do_emit = true;
+            if (g < wbase || g - wbase >= 32) {  // not in the window (wbase == ~0: none yet): refill
+                const uint64_t end4 = (g + 4) & ~3ull;  // window ends at the next 4-byte boundary
+                wbase = end4 >= 32 ? end4 - 32 : 0;
+                ph = P_CHARS;
             } else {
-                n_jumps++;
-                quirk = (k < R && H_k == c);
-                qbeg = li.qbeg;
-                qend = li.qend;
-                ph = PH_CNT;
-                continue;
+                const uint32_t wi = (uint32_t)(g - wbase);
+                const uint64_t wsel = (wi & 16) ? ((wi & 8) ? w3 : w2) : ((wi & 8) ? w1 : w0);
+                c = (uint32_t)(wsel >> ((wi & 7) * 8)) & 0xffu;
+                const LetterInfo li = s_let[c];
+                if (li.lid == NO_LETTER) {  // number_of_letter(c) == 0   (:249)
+                    length = 0;
+                    if (MODE == SPX_MODE_MS) {
+                        sample = 0;                 // :581
+                        if (DOC) doc = ix.doc_at0;  // :641-642
+                    }
+                    k0 = li.frun;  // LF(pos, c) = F[c] + 0
+                    offp = li.foff;
+                    do_emit = true;
+                } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
+                    length++;
+                    sample--;  // :582 (wraps, Appendix C3)
+                    k0 = LFrun_k;
+                    offp = LFoff_k + off;
+                    do_emit = true;
+                } else if (k < R && H_k == c && S_k + off >= THR_k) {
+                    // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
+                    // branch runs, select(rank(pos,c),c) == pos, and pos >= thr keeps it there
+                    n_jumps++;
+                    length = 0;
+                    doc = docs_k & 0xffff;  // start_runs_doc[run of pos]
+                    if (MODE == SPX_MODE_MS) {
+                        ph = P_SAMP;  // sample = samples_start[run of pos]
+                    } else {
+                        k0 = LFrun_k;
+                        offp = LFoff_k + off;
+                        do_emit = true;
+                    }
+                } else {
+                    n_jumps++;
+                    quirk = (k < R && H_k == c);
+                    qbeg = li.qbeg;
+                    qend = li.qend;
+                    ph = P_CNT;
+                }
             }
         }
 
         if (do_emit) {
             const uint32_t xi = x - 1;
+            const uint64_t gi = base + xi;
             if (MODE == SPX_MODE_PML) {
-                b.out_lengths[base + xi] = length;  // lengths[m-i-1] = length   (:281)
+                // lengths[m-i-1] = length (:281), staged 8 at a time (u16) when the read is short
+                if (m < 65536) {
+                    const uint32_t slot = (uint32_t)gi & 7;
+                    const uint64_t v = (uint64_t)length << ((slot & 3) * 16);
+                    if (slot & 4)
+                        ob_hi |= v;
+                    else
+                        ob_lo |= v;
+                    if (slot == 0 || xi == 0) {
+                        // flush the group [g8, g8+8) restricted to this read's range
+                        const uint64_t g8 = gi & ~7ull;
+                        uint32_t* o = b.out_lengths + g8;
+                        const bool full_lo = (g8 >= base) && (g8 + 3 < base + m);
+                        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 < base + m);
+                        if (full_lo) {
+                            uint4 v4 = make_uint4((uint32_t)ob_lo & 0xffff, (uint32_t)(ob_lo >> 16) & 0xffff,
+                                                  (uint32_t)(ob_lo >> 32) & 0xffff, (uint32_t)(ob_lo >> 48));
+                            *reinterpret_cast<uint4*>(o) = v4;
+                        }
+                        if (full_hi) {
+                            uint4 v4 = make_uint4((uint32_t)ob_hi & 0xffff, (uint32_t)(ob_hi >> 16) & 0xffff,
+                                                  (uint32_t)(ob_hi >> 32) & 0xffff, (uint32_t)(ob_hi >> 48));
+                            *reinterpret_cast<uint4*>(o + 4) = v4;
+                        }
+                        if (!full_lo || !full_hi) {
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                const bool covered = t < 4 ? full_lo : full_hi;
+                                const uint64_t gt = g8 + t;
+                                if (!covered && gt >= gi && gt < base + m) {
+                                    const uint64_t wv = t < 4 ? ob_lo : ob_hi;
+                                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
+                                }
+                            }
+                        }
+                        ob_lo = ob_hi = 0;
+                    }
+                } else {
+                    b.out_lengths[gi] = length;
+                }
             } else {
-                b.out_pointers[base + xi] = sample;  // :618
+                b.out_pointers[gi] = sample;  // :618
             }
-            if (DOC) b.out_docs[base + xi] = doc;  // :336 / :677
+            if (DOC) b.out_docs[gi] = doc;  // :336 / :677
             if (want_class) {
                 if (xi < bin_lo) {  // crossed into the previous bin (descending index)
                     if (bin_max >= b.max_value_thr)
@@ -317,9 +398,10 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     sum_max += bin_max;
                     b.out_class[rd] = spx_class{sum_max, above, below};
                 }
-                ph = PH_NEW;
+                rd += nlanes;
+                ph = rd < b.nreads ? P_READ : P_DONE;
             } else {
-                ph = PH_LAND;
+                ph = P_LAND;
             }
         }
     }
