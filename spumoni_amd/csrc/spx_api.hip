@@ -99,7 +99,9 @@ void spx_index_free(spx_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->rows) (void)hipFree(ix->rows);
-    if (ix->cnt) (void)hipFree(ix->cnt);
+    if (ix->fat) (void)hipFree(ix->fat);
+    if (ix->dirdocs) (void)hipFree(ix->dirdocs);
+    if (ix->rundocs) (void)hipFree(ix->rundocs);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);
     if (ix->samples) (void)hipFree(ix->samples);
     if (ix->dirrows) (void)hipFree(ix->dirrows);

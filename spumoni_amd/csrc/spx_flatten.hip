@@ -114,12 +114,14 @@ __global__ void k_letters(const uint8_t* Hs, const uint64_t* LFs, const uint64_t
     out[c] = li;
 }
 
-// one thread per run, in (letter, run index) order: assemble the 32-byte row
+// one thread per run, in (letter, run index) order: the 16-byte row of the run and the
+// jump row of its directory position
 __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint64_t* LFs,
                              const uint64_t* S, const uint64_t* lens, const uint32_t* nzpos,
                              const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
                              const uint64_t* de, const LetterInfo* letters, uint64_t r, uint64_t n,
-                             Row* rows, DirRow* dirrows, unsigned long long* err) {
+                             Row* rows, JumpRow* dirrows, uint32_t* dirdocs, uint32_t* rundocs,
+                             unsigned long long* err) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
     uint32_t k = Qall[i];
@@ -128,6 +130,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
     // LF(S[k]) = F[c] + (number of c before run k) = exclusive scan in (letter, run) order
     uint64_t lf = LFs[i];
     uint64_t dst = upper_bound_u64(S, r, lf) - 1;
+    const uint64_t soff = lf - S[dst];
     // thr_bv::operator[]: rank = number of c-runs before k; 0 -> 0, else the
     // (rank-1)-th STORED (non-zero) threshold of the letter (thresholds_ds.hpp:484-488)
     uint64_t rank = i - li.qbeg;
@@ -139,38 +142,47 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
             atomicAdd(err, 1ull);  // select past the last stored threshold: undefined upstream
         } else {
             thr = T[base + rank - 1];
-            if (thr > n) atomicAdd(err, 1ull);
+            if (thr > n) {
+                atomicAdd(err, 1ull);
+                thr = n;
+            }
         }
     }
-    uint64_t d0 = ds ? ds[k] : 0, d1 = de ? de[k] : 0;
-    if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
-    rows[k] = pack_row(S[k], c, lens[k], (uint32_t)dst, lf - S[dst], thr, (uint32_t)d0, (uint32_t)d1);
-    // directory row i: successor landing = LF(S[k]); predecessor landing = that position - 1
-    // (= LF of the last character of the previous run in directory order)
-    const uint64_t soff = lf - S[dst];
-    uint64_t prun = 0, poff = 0, dprev = 0;
+    // threshold as (run, offset) so that the walk never needs absolute positions
+    uint64_t trun = 0, toff = 0;
+    if (thr > 0) {
+        trun = thr >= n ? r : upper_bound_u64(S, r, thr) - 1;
+        toff = thr - S[trun];
+    }
+    rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k]);
+    // predecessor landing = LF(S[k]) - 1 = LF of the last character of the previous run in
+    // directory order
+    bool psame = false;
+    uint64_t poff = 0;
     if (i > 0) {
-        if (soff > 0) {
-            prun = dst;
-            poff = soff - 1;
-        } else {
-            prun = dst - 1;  // lf > 0 here, so dst >= 1
-            poff = S[dst] - S[dst - 1] - 1;
-        }
-        dprev = de ? de[Qall[i - 1]] : 0;
+        psame = soff > 0;
+        poff = psame ? soff - 1 : S[dst] - S[dst - 1] - 1;  // lf > 0 here, so dst >= 1 when !psame
     }
-    dirrows[i] = pack_dirrow(k, thr, (uint32_t)dst, soff, (uint32_t)prun, poff, (uint32_t)d0, (uint32_t)dprev);
-    if (i + 1 == r) {  // sentinel directory row r: LF image n, predecessor = position n-1
-        const uint64_t dlast = de ? de[k] : 0;
-        DirRow sd = pack_dirrow((uint32_t)r, 0, (uint32_t)r, 0, (uint32_t)(r - 1), S[r] - S[r - 1] - 1, 0,
-                                (uint32_t)dlast);
+    dirrows[i] = pack_jumprow(k, (uint32_t)trun, toff, (uint32_t)dst, soff, psame, poff, (uint32_t)i);
+    if (dirdocs) {
+        uint64_t d0 = ds[k], d1 = de[k], dp = i > 0 ? de[Qall[i - 1]] : 0;
+        if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
+        dirdocs[i] = (uint32_t)d0 | ((uint32_t)dp << 16);
+        rundocs[k] = (uint32_t)d0 | ((uint32_t)d1 << 16);
+        if (i + 1 == r) {
+            for (int t = 0; t < 4; ++t) dirdocs[r + t] = (uint32_t)d1 << 16;
+            for (int t = 0; t < 4; ++t) rundocs[r + t] = 0;
+        }
+    }
+    if (i + 1 == r) {  // sentinel jump row r: LF image n, predecessor = position n-1
+        JumpRow sd = pack_jumprow((uint32_t)r, 0, 0, (uint32_t)r, 0, false, S[r] - S[r - 1] - 1, (uint32_t)r);
         for (int t = 0; t < 4; ++t) dirrows[r + t] = sd;
     }
 }
 
-__global__ void k_sentinel_rows(Row* rows, uint64_t r, uint64_t n) {
+__global__ void k_sentinel_rows(Row* rows, uint64_t r) {
     int t = threadIdx.x;
-    if (t < ROW_PAD) rows[r + t] = pack_row(n, 0, MASK40, (uint32_t)r, 0, 0, 0, 0);
+    if (t < ROW_PAD) rows[r + t] = pack_row(0, MASK40, (uint32_t)r, 0, true);
 }
 
 // block count table: cnt[lid][b] = directory offset of the first c-run with index >= b << s
@@ -185,6 +197,12 @@ __global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const Letter
     for (int64_t x = pb + 1; x <= b; ++x) row[x] = (uint32_t)i;
     if (i + 1 == li.qend)
         for (int64_t x = b + 1; x < (int64_t)nblk; ++x) row[x] = li.qend;
+}
+
+// fat[lid][b] = copy of the jump row of the first c-run at or after block b
+__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, uint64_t total, JumpRow* fat) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < total) fat[i] = dirrows[cnt[i]];
 }
 
 __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
@@ -309,29 +327,46 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     for (auto& li : hl)
         if (li.lid != NO_LETTER) nletters++;
 
-    // rows
+    // rows + jump rows
+    const bool docs = d_ds && d_de;
     SPX_HIP(hipMalloc((void**)&ix->rows, (r + ROW_PAD) * sizeof(Row)));
-    SPX_HIP(hipMalloc((void**)&ix->dirrows, (r + ROW_PAD) * sizeof(DirRow)));
+    SPX_HIP(hipMalloc((void**)&ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow)));
+    if (docs) {
+        SPX_HIP(hipMalloc((void**)&ix->dirdocs, (r + ROW_PAD) * 4));
+        SPX_HIP(hipMalloc((void**)&ix->rundocs, (r + ROW_PAD) * 4));
+    }
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters, r,
-                                              n, ix->rows, ix->dirrows, err.as<unsigned long long>());
-    k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, n);
+                                              n, ix->rows, ix->dirrows, ix->dirdocs, ix->rundocs,
+                                              err.as<unsigned long long>());
+    k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r);
+    SPX_HIP(hipStreamSynchronize(st));
+    (void)hipFree(T.p);
+    T.p = nullptr;
+    (void)hipFree(nzpos.p);
+    nzpos.p = nullptr;
+    (void)hipFree(LFs.p);
+    LFs.p = nullptr;
 
-    // directory block size: about half a run of a typical letter per block, so that most
-    // blocks hold no run of the wanted letter and the walk can skip the Q window
+    // directory block size: about half a run of a typical letter per block, so that for
+    // most jumps the block's fat entry already IS the successor run
     uint32_t bshift = 2;
     while ((2u << bshift) <= nletters && bshift < 16) bshift++;
     const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
-    SPX_HIP(hipMalloc((void**)&ix->cnt, (uint64_t)nletters * nblk * 4 + 64));
+    const uint64_t nfat = (uint64_t)nletters * nblk;
+    DevBuf cnt;
+    SPX_HIP(cnt.alloc(nfat * 4 + 64));
     k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, bshift,
-                                            nblk, ix->cnt);
+                                            nblk, cnt.as<uint32_t>());
+    SPX_HIP(hipMalloc((void**)&ix->fat, (nfat + 2) * sizeof(JumpRow)));
+    k_fill_fat<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, nfat, ix->fat);
     SPX_HIP(hipMalloc((void**)&ix->q_alloc, (r + 1 + Q_PAD) * 4));
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
-    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(DirRow)) + (uint64_t)nletters * nblk * 4 +
-                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo);
-    uint64_t last_esa = 0;
+    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * sizeof(JumpRow) +
+                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 8 : 0);
+    uint64_t last_esa = 0, last_de = 0, first_ds = 0;
     if (d_ssa && d_esa) {
         SPX_HIP(hipMalloc((void**)&ix->samples, (r + 2) * sizeof(SamplePair)));
         SPX_HIP(hipMalloc((void**)&ix->ss_by_run, (r + 4) * 8));
@@ -341,12 +376,12 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8;
         ix->has_samples = true;
     }
-    ix->has_docs = d_ds && d_de;
+    ix->has_docs = docs;
+    if (docs) {
+        SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
+    }
 
-    // scalars of the initial state (compute_ms_pml.cpp:243, 298, 575, 641-642)
-    Row last_row, first_row;
-    SPX_HIP(hipMemcpyAsync(&last_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipMemcpyAsync(&first_row, ix->rows, sizeof(Row), hipMemcpyDeviceToHost, st));
     unsigned long long herr = 0;
     SPX_HIP(hipMemcpyAsync(&herr, err.p, 8, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipStreamSynchronize(st));
@@ -357,13 +392,16 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         return SPX_E_FORMAT;
     }
 
+    // scalars of the initial state (compute_ms_pml.cpp:243, 298, 575, 641-642)
     DevIndex& v = ix->view;
     v.rows = ix->rows;
     v.dirrows = ix->dirrows;
-    v.ss_by_run = ix->ss_by_run;
-    v.cnt = ix->cnt;
+    v.fat = ix->fat;
     v.Q = ix->q_alloc + 1;
     v.samples = ix->samples;
+    v.ss_by_run = ix->ss_by_run;
+    v.dirdocs = ix->dirdocs;
+    v.rundocs = ix->rundocs;
     v.letters = ix->letters;
     v.text = nullptr;
     v.n_text = 0;
@@ -372,10 +410,10 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.nblk = nblk;
     v.bshift = bshift;
     v.init_k = (uint32_t)(r - 1);
-    v.init_off = row_len(last_row) - 1;
+    v.init_off = last_len - 1;
     v.init_sample = ix->samples ? (last_esa + 1) % n : 0;
-    v.init_doc = row_docE(last_row);
-    v.doc_at0 = row_docS(first_row);
+    v.init_doc = (uint32_t)last_de;
+    v.doc_at0 = (uint32_t)first_ds;
     ix->device_bytes = bytes;
     return SPX_OK;
 }

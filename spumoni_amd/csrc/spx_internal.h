@@ -52,11 +52,13 @@ struct spx_index {
     uint64_t n = 0, r = 0;
     bool has_samples = false, has_docs = false;
     spx::Row* rows = nullptr;
-    uint32_t* cnt = nullptr;
     uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
-    spx::DirRow* dirrows = nullptr;
+    spx::JumpRow* dirrows = nullptr;
+    spx::JumpRow* fat = nullptr;
     spx::SamplePair* samples = nullptr;
     uint64_t* ss_by_run = nullptr;
+    uint32_t* dirdocs = nullptr;
+    uint32_t* rundocs = nullptr;
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;
     uint64_t n_text = 0;
@@ -68,6 +70,8 @@ struct spx_index {
     uint64_t device_bytes = 0;
     int variant = 0;      // 0 auto, 1 lane-per-read, 64 wave-per-read
     int waves_per_cu = 0; // 0 = default occupancy target
+    int occ_blocks[4] = {0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant
+    int num_cus = 0;
     std::mutex mu;
 };
 

@@ -6,20 +6,22 @@
 // is ours (spx_layout.h).
 //
 // k_walk_lanes -- "lane-per-read state machine".
-// The walk of one read is a chain of dependent 32-byte gathers (1 per matching
-// character, 3-4 per threshold jump), and MI355X's random-gather ceiling is
-// ~50 G L2-line fills/s (tools/gather_bench.hip) reached with >= 64k chains in
-// flight -- far more chains than the 8k wavefronts the chip holds.  So every
-// LANE owns one read and runs a small state machine.  Each loop iteration
-// issues exactly ONE 32-byte gather per lane, from a single load site, at the
-// address the lane's current phase asks for:
+// The walk of one read is a chain of dependent small gathers (1 per matching
+// character, 2-3 per threshold jump), and MI355X's random-gather ceiling is
+// ~50 G 16-byte gathers/s (41 G/s for 32-byte ones; tools/gather_bench.hip),
+// reached only with >= 64k chains in flight -- far more chains than the 8k
+// wavefronts the chip holds.  So every LANE owns one read and runs a small
+// state machine.  Each loop iteration issues exactly ONE gather per lane, from
+// a single load site, at the address the lane's current phase asks for:
 //
-//   P_READ   offsets[rd], offsets[rd+1]         (next read of this lane)
-//   P_CHARS  32 characters of the read          (refill, every <= 32 steps)
-//   P_LAND   rows[k0]                           (run the LF step lands in)
-//   P_CNT    cnt[letter][k >> bshift]           (directory block bounds)
-//   P_QS     Q[lo-1 .. lo+6]                    (only if the block holds c-runs)
-//   P_DIR    dirrows[j]                         (threshold + both jump landings)
+//   P_READ   offsets[rd], offsets[rd+1]   16 B  (next read of this lane)
+//   P_CHARS  32 characters of the read    32 B  (refill, every <= 32 steps)
+//   P_LAND   rows[k0]                     16 B  (run the LF step lands in)
+//   P_FAT    fat[letter][k >> bshift]     32 B  (jump row of the first c-run at or
+//                                                after the block: usually THE answer)
+//   P_QS     Q[j .. j+8)                  32 B  (only if the block holds c-runs < k)
+//   P_DIR    dirrows[j]                   32 B  (only after P_QS)
+//   P_AUX / P_SAMP                              (MS samples / document ids)
 //
 // then consumes it and moves to the next phase.  Because the load site is
 // unique, all 64 lanes of a wave always have their gather in flight together
@@ -35,11 +37,12 @@ enum : uint32_t {
     P_READ = 0,
     P_CHARS = 1,
     P_LAND = 2,
-    P_CNT = 3,
+    P_FAT = 3,
     P_QS = 4,
     P_DIR = 5,
-    P_SAMP = 6,
-    P_DONE = 7
+    P_AUX = 6,
+    P_SAMP = 7,
+    P_DONE = 8
 };
 
 constexpr int WALK_TPB = 256;
@@ -57,13 +60,14 @@ __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) {
 // ---------------------------------------------------------------------------
 template <int MODE, bool DOC>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
+    constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
     __shared__ LetterInfo s_let[256];
     for (int t = threadIdx.x; t < 256; t += WALK_TPB) s_let[t] = ix.letters[t];
     __syncthreads();
 
     const char* const rows_b = reinterpret_cast<const char*>(ix.rows);
     const char* const dir_b = reinterpret_cast<const char*>(ix.dirrows);
-    const char* const cnt_b = reinterpret_cast<const char*>(ix.cnt);
+    const char* const fat_b = reinterpret_cast<const char*>(ix.fat);
     const char* const q_b = reinterpret_cast<const char*>(ix.Q);
     const char* const seq_b = reinterpret_cast<const char*>(b.seqs);
     const char* const off_b = reinterpret_cast<const char*>(b.offs);
@@ -76,8 +80,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint64_t base = 0;
     uint32_t m = 0, x = 0;  // x = characters still to search; next one is index x-1
     // landed position: run k, offset off; fields of row k
-    uint32_t k = 0, H_k = 0, LFrun_k = 0, docs_k = 0;
-    uint64_t off = 0, S_k = 0, LFoff_k = 0, THR_k = 0;
+    uint32_t k = 0, H_k = 0, LFrun_k = 0;
+    uint64_t off = 0, LFoff_k = 0;
+    bool thr_ok_k = true;
     // landing target
     uint32_t k0 = 0;
     uint64_t offp = 0;
@@ -85,11 +90,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t length = 0, doc = 0;
     uint64_t sample = 0;
     // jump bookkeeping
-    uint32_t c = 0, lo = 0, hi = 0, jdir = 0, qbeg = 0, qend = 0;
+    uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0;
     bool quirk = false;
     // character window: 32 bytes starting at byte offset wbase of seqs
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, wbase = 0;
-    // output staging (PML): 8 u16 values of the aligned group [obase, obase+8)
+    // output staging (PML): 8 u16 values of the aligned group of 8 outputs
     uint64_t ob_lo = 0, ob_hi = 0;
     // classifier
     uint32_t bin_lo = 0, bin_max = 0, above = 0, below = 0;
@@ -102,51 +107,46 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     while (ph != P_DONE) {
         // ---- the one gather of this iteration -------------------------------
         const char* p0;
-        const char* p1;
         if (ph == P_LAND) {
             p0 = rows_b + (uint64_t)k0 * sizeof(Row);
-            p1 = p0 + 16;
+        } else if (ph == P_FAT) {
+            p0 = fat_b + ((uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift)) * sizeof(JumpRow);
         } else if (ph == P_DIR) {
-            p0 = dir_b + (uint64_t)jdir * sizeof(DirRow);
-            p1 = p0 + 16;
-        } else if (ph == P_CNT) {
-            p0 = cnt_b + ((uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift)) * 4;
-            p1 = p0;
+            p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
         } else if (ph == P_QS) {
-            const int64_t at = (int64_t)(hi - lo <= 6 ? lo : lo + ((hi - lo) >> 1)) - 1;
-            p0 = q_b + at * 4;
-            p1 = p0 + 16;
+            p0 = q_b + (uint64_t)jdir * 4;
         } else if (ph == P_CHARS) {
             p0 = seq_b + wbase;
-            p1 = p0 + 16;
         } else if (ph == P_READ) {
             p0 = off_b + rd * 8;
-            p1 = p0;
-        } else {  // P_SAMP
+        } else if (MODE == SPX_MODE_MS && ph == P_SAMP) {
             p0 = reinterpret_cast<const char*>(ix.ss_by_run + k);
-            p1 = p0;
+        } else if (MODE == SPX_MODE_MS && ph == P_AUX) {
+            p0 = reinterpret_cast<const char*>(ix.samples + jdir);
+        } else {
+            p0 = rows_b;
         }
+        const bool wide = (ph == P_FAT) | (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS);
         const V16 ga = *reinterpret_cast<const V16*>(p0);
-        const V16 gb = *reinterpret_cast<const V16*>(p1);
-        SamplePair sp{0, 0};
-        if (MODE == SPX_MODE_MS) {
-            // MS: the samples of the directory position travel with the directory row
-            const SamplePair* ps = ix.samples + (ph == P_DIR ? jdir : 0);
-            sp = *ps;
+        V16 gb{0, 0, 0, 0};
+        if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
+        uint32_t dd = 0;
+        if (DOC) {
+            const uint32_t* pd = (ph == P_SAMP) ? ix.rundocs + k : ix.dirdocs + ((ph == P_AUX) ? jdir : 0);
+            dd = *pd;
         }
         const uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
         const uint64_t g2 = u64of(gb.x, gb.y), g3 = u64of(gb.z, gb.w);
 
         // ---- consume ---------------------------------------------------------
-        bool do_emit = false;  // a character's result is final -> write it and advance
-        bool do_step = false;  // landed on a run -> look at the next character
+        bool do_emit = false;    // a character's result is final -> write it and advance
+        bool do_step = false;    // landed on a run -> look at the next character
+        bool do_decide = false;  // g0..g3 hold the jump row that answers the jump
         if (ph == P_LAND) {
             n_rows++;
             Row ra;
             ra.q0 = g0;
             ra.q1 = g1;
-            ra.q2 = g2;
-            ra.q3 = g3;
             const uint64_t len = row_len(ra);
             if (offp >= len) {  // LF image lies in a later run: skip this row
                 offp -= len;
@@ -154,91 +154,45 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else {
                 k = k0;
                 off = offp;
-                S_k = row_S(ra);
                 H_k = row_H(ra);
                 LFrun_k = row_LFrun(ra);
                 LFoff_k = row_LFoff(ra);
-                THR_k = row_THR(ra);
-                docs_k = row_docS(ra) | (row_docE(ra) << 16);
+                thr_ok_k = row_thr_ok(ra);
                 do_step = true;
             }
-        } else if (ph == P_DIR) {
-            // compute_ms_pml.cpp:253-278 (PML) / :585-615 (MS) on the flat layout
+        } else if (ph == P_FAT) {
             n_dir++;
-            DirRow dr;
-            dr.d0 = g0;
-            dr.d1 = g1;
-            dr.d2 = g2;
-            dr.d3 = g3;
-            const uint64_t pos = S_k + off;  // sentinel row r has S = n, off = 0
-            const bool has_succ = jdir < qend;  // rnk < number_of_letter(c)   (:259)
-            uint64_t thr = ix.n + 1;            // :254
-            if (!quirk) {
-                if (has_succ) {
-                    thr = dir_THR(dr);
-                    length = 0;
-                    sample = sp.ss;        // samples_start[run_of_j]  (:601)
-                    doc = dir_docS(dr);    // start_runs_doc[run_of_j] (:317)
-                    k0 = dir_sLFrun(dr);   // next_pos = j; LF(j, c)
-                    offp = dir_sLFoff(dr);
-                }
-                if (pos < thr) {  // :270  -> select(rnk-1, c): last character of the previous c-run
-                    n_pred++;
-                    if (jdir <= qbeg) n_err++;  // rnk-- below zero: undefined upstream
-                    length = 0;
-                    sample = sp.se;        // samples_last[run_of_j]  (:611)
-                    doc = dir_docEp(dr);   // end_runs_doc[run_of_j]  (:327)
-                    k0 = dir_pLFrun(dr);
-                    offp = dir_pLFoff(dr);
-                }
+            JumpRow e;
+            e.d0 = g0;
+            e.d2 = g2;
+            e.d3 = g3;
+            const uint32_t ej = jr_j(e);
+            // the block's first c-run is the successor unless it lies before k (or is k
+            // itself when the walk sits on a c-run: byte >= 128, Appendix C1)
+            if (ej >= qend || jr_q(e) > k || (quirk && jr_q(e) == k)) {
+                jdir = ej;
+                do_decide = true;
             } else {
-                // byte >= 128 equal to the head of its run with pos < thresholds[run]
-                // (Appendix C1; only reachable with inconsistent thresholds): jdir is the
-                // directory position of run k when off == 0, of the next c-run when off > 0
-                n_pred++;
-                length = 0;
-                sample = sp.se;
-                if (off > 0) {  // select(rnk-1, c) = pos - 1, still inside run k
-                    doc = docs_k >> 16;
-                    k0 = LFrun_k;
-                    offp = LFoff_k + off - 1;
-                } else {
-                    if (jdir <= qbeg) n_err++;
-                    doc = dir_docEp(dr);
-                    k0 = dir_pLFrun(dr);
-                    offp = dir_pLFoff(dr);
-                }
-            }
-            do_emit = true;
-        } else if (ph == P_CNT) {
-            n_dir++;
-            lo = (uint32_t)g0;
-            hi = (uint32_t)(g0 >> 32);
-            if (hi == lo) {  // no c-run inside the block: the successor is directory entry lo
-                jdir = lo;
-                ph = P_DIR;
-            } else {
+                jdir = ej + 1;  // scan the directory from the next c-run on
                 ph = P_QS;
             }
         } else if (ph == P_QS) {
             n_dir++;
             const uint32_t e[8] = {(uint32_t)g0, (uint32_t)(g0 >> 32), (uint32_t)g1, (uint32_t)(g1 >> 32),
                                    (uint32_t)g2, (uint32_t)(g2 >> 32), (uint32_t)g3, (uint32_t)(g3 >> 32)};
-            if (hi - lo <= 6) {
-                // window holds Q[lo-1 .. lo+6]; j = lo + number of c-runs of the block with index < k
-                uint32_t cntlt = 0;
+            // window holds Q[jdir .. jdir+8): skip the c-runs with index < k (<= k when sitting
+            // on a c-run and looking for that very run)
+            uint32_t skip = 0;
 #pragma unroll
-                for (int t = 1; t <= 6; ++t) cntlt += ((uint32_t)t <= hi - lo && e[t] < k) ? 1u : 0u;
-                jdir = lo + cntlt;
-                if (quirk && off > 0) jdir++;  // see P_DIR: entry after run k carries samples_last[k]
-                ph = P_DIR;
-            } else {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (e[1] < k)
-                    lo = mid + 1;
-                else
-                    hi = mid;
+            for (int t = 0; t < 8; ++t) {
+                const bool before = quirk ? (e[t] < k) : (e[t] < k);
+                skip += (jdir + t < qend && before && skip == (uint32_t)t) ? 1u : 0u;
             }
+            jdir += skip;
+            if (skip < 8) ph = P_DIR;
+        } else if (ph == P_DIR) {
+            n_dir++;
+            do_decide = true;
         } else if (ph == P_CHARS) {
             w0 = g0;
             w1 = g1;
@@ -270,11 +224,73 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 }
                 ph = P_LAND;
             }
-        } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1), MS mode
-            sample = g0;  // samples_start[run of pos]
+        } else if (ph == P_AUX) {
+            // side data of directory position jdir: {samples_start[Q[j]], samples_last[Q[j-1]]}
+            // and {start_runs_doc[Q[j]], end_runs_doc[Q[j-1]]}
+            if (MODE == SPX_MODE_MS) sample = aux_take ? g1 : g0;  // :601 / :611
+            if (DOC) doc = aux_take ? (dd >> 16) : (dd & 0xffff);   // :317 / :327
+            do_emit = true;
+        } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1): stays there
+            if (MODE == SPX_MODE_MS) sample = g0;  // samples_start[run of pos]
+            if (DOC) doc = dd & 0xffff;            // start_runs_doc[run of pos]
             k0 = LFrun_k;
             offp = LFoff_k + off;
             do_emit = true;
+        }
+
+        if (do_decide) {
+            // compute_ms_pml.cpp:253-278 (PML) / :585-615 (MS) on the flat layout
+            JumpRow e;
+            e.d0 = g0;
+            e.d1 = g1;
+            e.d2 = g2;
+            e.d3 = g3;
+            const bool has_succ = jdir < qend;  // rnk < number_of_letter(c)   (:259)
+            const uint32_t trun = jr_THRrun(e);
+            // pos < thr, with thr = n + 1 when there is no successor (:254, :270)
+            const bool below_thr = !has_succ || (k < trun) || (k == trun && off < jr_THRoff(e));
+            const uint32_t srun = jr_sLFrun(e);
+            const uint64_t soff = jr_sLFoff(e);
+            length = 0;
+            aux_take = 0;
+            if (!quirk) {
+                if (!below_thr) {  // next_pos = first position of the next c-run; LF of it
+                    k0 = srun;
+                    offp = soff;
+                } else {  // select(rnk-1, c): last position of the previous c-run; LF of it
+                    n_pred++;
+                    if (jdir <= qbeg) n_err++;  // rnk-- below zero: undefined upstream
+                    aux_take = 1;
+                    const bool ps = jr_psame(e);
+                    k0 = ps ? srun : srun - 1;
+                    offp = ps ? soff - 1 : jr_pLFoff(e);
+                }
+            } else {
+                // the walk sits on run k whose head equals c >= 128 (Appendix C1) and
+                // thresholds[k] > S[k] (inconsistent thresholds): jdir is k's directory position
+                if (!below_thr) {  // select(rank(pos,c),c) == pos: stay
+                    k0 = LFrun_k;
+                    offp = LFoff_k + off;
+                } else if (off > 0) {  // select(rnk-1, c) = pos - 1, still inside run k
+                    n_pred++;
+                    aux_take = 1;
+                    jdir++;  // directory entry after k carries samples_last[k] / end_runs_doc[k]
+                    k0 = LFrun_k;
+                    offp = LFoff_k + off - 1;
+                } else {
+                    n_pred++;
+                    if (jdir <= qbeg) n_err++;
+                    aux_take = 1;
+                    const bool ps = jr_psame(e);
+                    k0 = ps ? srun : srun - 1;
+                    offp = ps ? soff - 1 : jr_pLFoff(e);
+                }
+            }
+            if (AUX) {
+                ph = P_AUX;
+            } else {
+                do_emit = true;
+            }
         }
 
         if (do_step) {
@@ -304,14 +320,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     k0 = LFrun_k;
                     offp = LFoff_k + off;
                     do_emit = true;
-                } else if (k < R && H_k == c && S_k + off >= THR_k) {
+                } else if (k < R && H_k == c && thr_ok_k) {
                     // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
-                    // branch runs, select(rank(pos,c),c) == pos, and pos >= thr keeps it there
+                    // branch runs, select(rank(pos,c),c) == pos, and thresholds[k] <= S[k] <= pos
+                    // keeps it there
                     n_jumps++;
                     length = 0;
-                    doc = docs_k & 0xffff;  // start_runs_doc[run of pos]
-                    if (MODE == SPX_MODE_MS) {
-                        ph = P_SAMP;  // sample = samples_start[run of pos]
+                    if (AUX) {
+                        ph = P_SAMP;  // sample = samples_start[k], doc = start_runs_doc[k]
                     } else {
                         k0 = LFrun_k;
                         offp = LFoff_k + off;
@@ -322,7 +338,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     quirk = (k < R && H_k == c);
                     qbeg = li.qbeg;
                     qend = li.qend;
-                    ph = P_CNT;
+                    ph = P_FAT;
                 }
             }
         }
@@ -476,16 +492,24 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
 
 template <int MODE, bool DOC>
 int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
-    int occ = 0;
-    SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC>, WALK_TPB, 0));
-    if (occ < 1) occ = 1;
+    // resident blocks per CU and CU count are looked up once per index and kernel variant
+    const int slot = MODE * 2 + (DOC ? 1 : 0);
+    if (ix->occ_blocks[slot] == 0) {
+        int occ = 0;
+        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC>, WALK_TPB, 0));
+        ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
+    }
+    if (ix->num_cus == 0) {
+        hipDeviceProp_t prop;
+        SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+        ix->num_cus = prop.multiProcessorCount;
+    }
+    int occ = ix->occ_blocks[slot];
     if (ix->waves_per_cu > 0) {
         int want = ix->waves_per_cu / (WALK_TPB / 64);
         if (want >= 1 && want < occ) occ = want;
     }
-    hipDeviceProp_t prop;
-    SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
-    uint64_t grid = (uint64_t)occ * prop.multiProcessorCount;
+    uint64_t grid = (uint64_t)occ * ix->num_cus;
     uint64_t need = (args.nreads + WALK_TPB - 1) / WALK_TPB;
     if (need < grid) grid = need;
     if (grid == 0) grid = 1;
