@@ -51,6 +51,44 @@ __global__ void __launch_bounds__(256) k_chase(const uint4* __restrict__ tab, ui
     if (acc == 0x1234567) sink[0] = acc;
 }
 
+// calibration: two 16-byte gathers per iteration, either in the two 64-byte halves of
+// ONE random 128-byte-aligned line (SAME=1) or in two different random lines (SAME=0).
+// If the L2 fills whole 128-byte lines, SAME=1 costs one miss per iteration.
+template <int SAME>
+__global__ void __launch_bounds__(256) k_pair(const uint4* __restrict__ tab, uint64_t nlines, int iters,
+                                              uint64_t* sink) {
+    uint64_t idx = mix(blockIdx.x * 256ull + threadIdx.x + 1) % nlines;
+    uint64_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint64_t idx2 = SAME ? idx : mix(idx + 0x9e3779b97f4a7c15ull) % nlines;
+        uint4 v = tab[idx * 8];
+        uint4 w = tab[idx2 * 8 + 4];
+        uint64_t h = v.x ^ ((uint64_t)v.y << 32) ^ w.z;
+        acc += h;
+        idx = mix(h + idx + i) % nlines;
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+template <int SAME>
+void run_pair(const uint4* tab, uint64_t bytes, uint64_t* sink, int blocks_per_cu, int ncu) {
+    const uint64_t nlines = bytes / 128;
+    const int iters = 2000;
+    const int grid = blocks_per_cu * ncu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    k_pair<SAME><<<grid, 256>>>(tab, nlines, iters, sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double it = (double)grid * 256 * iters;
+    printf("PAIR %s 128B line, blocks/CU=%d: %8.2f G iterations/s (2 x 16 B gathers each), %llu iterations\n",
+           SAME ? "two halves of ONE" : "two DIFFERENT", blocks_per_cu, it / ms / 1e6, (unsigned long long)it);
+}
+
 __global__ void k_fill(uint4* tab, uint64_t n16) {
     uint64_t i = blockIdx.x * 256ull + threadIdx.x;
     if (i < n16) {
@@ -95,6 +133,15 @@ int main(int argc, char** argv) {
     k_fill<<<(unsigned)((bytes / 16 + 255) / 256), 256>>>(tab, bytes / 16);
     CK(hipDeviceSynchronize());
     const int ncu = prop.multiProcessorCount;
+    if (argc > 2) {  // calibration mode: one kernel shape only (for rocprofv3 --pmc)
+        const int mode = atoi(argv[2]);
+        if (mode == 0) run<16>(tab, bytes, sink, 4, ncu);
+        if (mode == 1) run_pair<1>(tab, bytes, sink, 4, ncu);
+        if (mode == 2) run_pair<0>(tab, bytes, sink, 4, ncu);
+        return 0;
+    }
+    run_pair<1>(tab, bytes, sink, 4, ncu);
+    run_pair<0>(tab, bytes, sink, 4, ncu);
     for (int bpc : {1, 2, 4, 8}) {
         run<16>(tab, bytes, sink, bpc, ncu);
         run<32>(tab, bytes, sink, bpc, ncu);
