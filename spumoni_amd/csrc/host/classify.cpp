@@ -1,0 +1,278 @@
+#include "classify.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+
+#include "index_files.hpp"
+#include "reads.hpp"
+
+namespace spumoni_host {
+
+IndexSet::~IndexSet() {
+    for (spx_index* p : ix) spx_index_free(p);
+}
+
+void IndexSet::load(const RunOptions& o) {
+    RawIndex raw;
+    std::string err;
+    if (!load_raw_index(o.ref_file, o.ms, raw, err)) fatal_error("%s", err.c_str());
+    if (o.use_doc && !load_doc_array(o.ref_file + ".doc", raw, err)) fatal_error("%s", err.c_str());
+    std::vector<uint8_t> text;
+    if (o.ms) {
+        if (o.text_file.empty() || !read_whole_file(o.text_file, text))
+            fatal_error("MS lengths need the indexed text as a plain file (set SPUMONI_TEXT): the SLP of the\n"
+                        "       reference is replaced by plain text in GPU memory (see DESIGN.md)");
+    }
+    n = raw.n;
+    r = raw.heads.size();
+    for (int dev : o.devices) {
+        spx_index* p = spx_index_from_runs(raw.heads.data(), raw.lens.data(), raw.thr.data(), r,
+                                           o.ms ? raw.ssa.data() : nullptr, o.ms ? raw.esa.data() : nullptr,
+                                           o.use_doc ? raw.doc_start.data() : nullptr,
+                                           o.use_doc ? raw.doc_end.data() : nullptr, 0, dev);
+        if (!p) fatal_error("%s", spx_last_error());
+        if (o.ms && spx_index_set_text(p, text.data(), text.size(), 0) != SPX_OK)
+            fatal_error("%s", spx_last_error());
+        ix.push_back(p);
+    }
+}
+
+size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promotions, bool use_dna_letters) {
+    size_t max_value_thr = (size_t)std::max(percentile_value, 3.0);
+    if (use_dna_letters)
+        max_value_thr++;
+    else if (is_pml && !use_dna_letters && !use_promotions)
+        max_value_thr += 4;
+    return max_value_thr;
+}
+
+namespace {
+
+// "<value> " for every value, the way std::ostream_iterator<size_t>(file, " ") writes them
+struct TextBuf {
+    std::string s;
+    void header(const std::string& id) {
+        s.push_back('>');
+        s.append(id);
+        s.push_back('\n');
+    }
+    void u64(uint64_t v) {
+        char tmp[24];
+        int p = 24;
+        do {
+            tmp[--p] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        s.append(tmp + p, 24 - p);
+        s.push_back(' ');
+    }
+    void newline() { s.push_back('\n'); }
+    void flush(std::ofstream& f) {
+        f.write(s.data(), (std::streamsize)s.size());
+        s.clear();
+    }
+};
+
+struct SuperBatch {
+    std::vector<std::string> ids;
+    std::vector<uint8_t> seqs;
+    std::vector<uint64_t> offs{0};
+    void clear() {
+        ids.clear();
+        seqs.clear();
+        offs.assign(1, 0);
+    }
+    size_t nreads() const { return ids.size(); }
+};
+
+struct Results {
+    std::vector<uint32_t> lengths, docs;
+    std::vector<uint64_t> pointers;
+    std::vector<spx_class> cls;
+};
+
+// contiguous, character-balanced shards: one per device, run concurrently
+void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
+    const size_t nreads = sb.nreads();
+    const uint64_t total = sb.offs.back();
+    res.lengths.assign(total, 0);
+    if (o.ms) res.pointers.assign(total, 0);
+    if (o.use_doc) res.docs.assign(total, 0);
+    if (o.write_report) res.cls.assign(nreads, spx_class{0, 0, 0});
+    const size_t ndev = set.ix.size();
+    std::vector<size_t> cut(ndev + 1, nreads);
+    cut[0] = 0;
+    for (size_t d = 1; d < ndev; ++d) {
+        const uint64_t target = total * d / ndev;
+        size_t c = std::lower_bound(sb.offs.begin(), sb.offs.end() - 1, target) - sb.offs.begin();
+        cut[d] = std::max(cut[d - 1], std::min(c, nreads));
+    }
+    std::vector<std::string> errors(ndev);
+    auto work = [&](size_t d) {
+        const size_t lo = cut[d], hi = cut[d + 1];
+        if (hi <= lo) return;
+        const uint64_t a = sb.offs[lo];
+        std::vector<uint64_t> offs(hi - lo + 1);
+        for (size_t q = lo; q <= hi; ++q) offs[q - lo] = sb.offs[q] - a;
+        int rc = spx_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data() + a, offs.data(),
+                                 hi - lo, res.lengths.data() + a, o.ms ? res.pointers.data() + a : nullptr,
+                                 o.use_doc ? res.docs.data() + a : nullptr,
+                                 o.write_report ? res.cls.data() + lo : nullptr, o.bin_size, max_value_thr);
+        if (rc != SPX_OK) errors[d] = spx_last_error();
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < ndev; ++d) th.emplace_back(work, d);
+    work(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errors)
+        if (!e.empty()) fatal_error("%s", e.c_str());
+}
+
+struct Outputs {
+    std::ofstream lengths, pointers, docs, report;
+    TextBuf tl, tp, td;
+};
+
+void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res) {
+    for (size_t q = 0; q < sb.nreads(); ++q) {
+        const uint64_t a = sb.offs[q], b = sb.offs[q + 1];
+        if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
+            out.td.header(sb.ids[q]);
+            for (uint64_t i = a; i < b; ++i) out.td.u64(res.docs[i]);
+            out.td.newline();
+        }
+        out.tl.header(sb.ids[q]);  // :1008-1010
+        for (uint64_t i = a; i < b; ++i) out.tl.u64(res.lengths[i]);
+        out.tl.newline();
+        if (o.ms) {  // :1190-1195
+            out.tp.header(sb.ids[q]);
+            for (uint64_t i = a; i < b; ++i) out.tp.u64(res.pointers[i]);
+            out.tp.newline();
+        }
+        if (o.write_report) {  // :1012-1020
+            const spx_class& c = res.cls[q];
+            const size_t nbins = (size_t)c.bins_above + c.bins_below;
+            const bool read_found = (c.bins_above / (c.bins_above + c.bins_below + 0.0) > 0.50);
+            out.report.precision(3);
+            out.report << std::setw(30) << std::left << sb.ids[q] << std::setw(15) << std::left
+                       << (read_found ? "FOUND" : "NOT_PRESENT") << std::setw(26) << std::left
+                       << (c.sum_max_bin_values + 0.0) / nbins << std::setw(12) << std::left
+                       << (size_t)c.bins_above << std::setw(12) << std::left << (size_t)c.bins_below << std::endl;
+        }
+        if (out.tl.s.size() > (8u << 20)) {
+            out.tl.flush(out.lengths);
+            if (o.ms) out.tp.flush(out.pointers);
+            if (o.use_doc) out.td.flush(out.docs);
+        }
+    }
+    out.tl.flush(out.lengths);
+    if (o.ms) out.tp.flush(out.pointers);
+    if (o.use_doc) out.td.flush(out.docs);
+}
+
+size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
+    out.lengths.open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
+    if (o.ms) out.pointers.open(o.pattern_file + ".pointers");
+    if (o.use_doc) out.docs.open(o.pattern_file + ".doc_numbers");
+    if (o.write_report) out.report.open(o.pattern_file + ".report", std::ofstream::out);
+    double percentile = 0.0;
+    std::string err;
+    // the reference does not check the stream either (:867-869): a missing null database
+    // leaves percentile_value at 0.0
+    (void)load_null_db(o.ref_file + (o.ms ? ".msnulldb" : ".pmlnulldb"), percentile, err);
+    const size_t max_value_thr = max_value_threshold(percentile, !o.ms, o.use_promotions, o.use_dna_letters);
+    if (o.write_report) {  // :877-886
+        out.report.precision(4);
+        out.report << std::setw(30) << std::left << "read id:" << std::setw(15) << std::left << "status:"
+                   << std::setw(19) << std::left << "avg max-value (thr=" << std::setw(2) << std::left
+                   << max_value_thr << std::setw(5) << std::left << "):" << std::setw(12) << std::left
+                   << "above thr:" << std::setw(12) << std::left << "below thr:" << std::endl;
+    }
+    return max_value_thr;
+}
+
+}  // namespace
+
+size_t classify_reads(IndexSet& set, const RunOptions& o) {
+    Outputs out;
+    const size_t max_value_thr = open_outputs_and_threshold(out, o);
+    ReadFile input(o.pattern_file);
+    SuperBatch sb;
+    Results res;
+    std::vector<ParsedRead> batch;
+    size_t num_reads = 0;
+    bool more = true;
+    while (more) {
+        // reader.loadBatch(input_file, 1000) (:903), many of them per GPU super-batch
+        more = input.next_batch(1000, batch);
+        if (more) {
+            for (ParsedRead& rd : batch) {
+                // make sure all characters are upper-case (:916-917)
+                for (char& ch : rd.seq) ch = (char)std::toupper((unsigned char)ch);
+                if (o.use_promotions || o.use_dna_letters)
+                    fatal_error("minimizer digestion of reads (-m / -a) is not available in this build: the\n"
+                                "       reference delegates it to dnbaker/bonsai, whose source is not available offline\n"
+                                "       (DESIGN.md). Digest the reads beforehand and run with -n.");
+                if (rd.seq.length() == 0) {  // :926-931
+                    std::cout << "\n\n";
+                    fatal_warning("%s was empty after digestion, commonly due to reads "
+                                  "consisting of mostly non-ACGT characters. Please remove "
+                                  "read or run SPUMONI without minimizer digestion.", rd.id.data());
+                }
+                sb.seqs.insert(sb.seqs.end(), rd.seq.begin(), rd.seq.end());
+                sb.offs.push_back(sb.seqs.size());
+                sb.ids.push_back(std::move(rd.id));
+            }
+        }
+        if (sb.nreads() > 0 && (!more || sb.seqs.size() >= o.super_batch_chars)) {
+            run_on_devices(set, o, sb, max_value_thr, res);
+            write_results(out, o, sb, res);
+            num_reads += sb.nreads();
+            sb.clear();
+        }
+    }
+    return num_reads;
+}
+
+size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
+    // :1219-1297: reads are separated by \x01; trailing text without a separator is ignored
+    RunOptions oo = o;
+    oo.use_doc = false;
+    oo.write_report = false;
+    Outputs out;
+    out.lengths.open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
+    if (o.ms) out.pointers.open(o.pattern_file + ".pointers");
+    std::vector<uint8_t> data;
+    if (!read_whole_file(o.pattern_file, data)) fatal_error("The following path is not valid: %s", o.pattern_file.data());
+    SuperBatch sb;
+    Results res;
+    size_t num_reads = 0, start = 0;
+    auto flush = [&]() {
+        if (sb.nreads() == 0) return;
+        run_on_devices(set, oo, sb, 0, res);
+        write_results(out, oo, sb, res);
+        sb.clear();
+    };
+    for (size_t i = 0; i < data.size(); ++i) {
+        if (data[i] == 0x01) {
+            sb.seqs.insert(sb.seqs.end(), data.begin() + start, data.begin() + i);
+            sb.offs.push_back(sb.seqs.size());
+            sb.ids.push_back("read_" + std::to_string(num_reads));
+            num_reads++;
+            start = i + 1;
+            if (sb.seqs.size() >= o.super_batch_chars) flush();
+        }
+    }
+    flush();
+    return num_reads;
+}
+
+}  // namespace spumoni_host

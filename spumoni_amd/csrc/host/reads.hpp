@@ -1,0 +1,56 @@
+// reads.hpp -- host-side read batching with the reference's BatchLoader semantics
+// (/root/reference/src/batch_loader.cpp:26-131), re-designed for feeding GPUs.
+//
+// The reference pulls ~1000-base batches out of an ifstream into a stringstream and
+// parses reads from it one at a time under an OpenMP critical section.  Here the
+// whole reads file is mapped once, line boundaries are found in one pass, and the
+// same batch segmentation is replayed over the line table (it decides which reads
+// exist at all for malformed input -- SURVEY Appendix C15/C16) while the reads are
+// appended to large super-batches for spx_query_batch.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace spumoni_host {
+
+enum class ReadFormat { NotClear, Fasta, Fastq };
+
+struct ParsedRead {
+    std::string id;   // header.substr(1, index of first whitespace)  -- keeps that whitespace (C6)
+    std::string seq;  // multi-line FASTA concatenated, trailing whitespace of each line stripped
+};
+
+class ReadFile {
+public:
+    // Loads the file into memory; throws std::runtime_error if it cannot be read.
+    explicit ReadFile(const std::string& path);
+
+    // Next batch of the reference's loadBatch(input, num_bases) segmentation, parsed with
+    // grabNextRead semantics.  Returns false when loadBatch would return false (end of
+    // input, or the FASTQ tail quirk C16).  `out` receives the reads of the batch in order.
+    bool next_batch(size_t num_bases, std::vector<ParsedRead>& out);
+
+    ReadFormat format() const { return format_; }
+
+private:
+    std::string data_;
+    std::vector<std::pair<size_t, size_t>> lines_;  // [begin, end) without the '\n'
+    bool ends_with_newline_ = false;
+    size_t next_line_ = 0;  // first line not yet consumed by a batch
+    bool eof_ = false;      // the reference stream would no longer be good()
+    ReadFormat format_ = ReadFormat::NotClear;
+
+    std::string_view line(size_t i) const {
+        return std::string_view(data_).substr(lines_[i].first, lines_[i].second - lines_[i].first);
+    }
+    void parse_batch(size_t first, size_t last, std::vector<ParsedRead>& out) const;
+};
+
+// error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)
+[[noreturn]] void fatal_error(const char* fmt, ...);
+[[noreturn]] void fatal_warning(const char* fmt, ...);
+
+}  // namespace spumoni_host

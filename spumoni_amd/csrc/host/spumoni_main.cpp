@@ -1,0 +1,257 @@
+// spumoni_main.cpp -- `spumoni run` on MI355X: the reference's command line
+// (/root/reference/src/spumoni.cpp:163-206, 733-779), option validation
+// (include/spumoni_main.hpp:252-329) and stderr/stdout log lines
+// (src/compute_ms_pml.cpp:1305-1382), on top of libspumoni_gpu.so.
+//
+// Differences that are ours, all additive:
+//   SPUMONI_GPUS=0,1,..   devices to use (default 0); reads are sharded, index replicated
+//   SPUMONI_TEXT=<file>   plain indexed text for the MS length extension (replaces <ref>.slp)
+//   the index is read from the raw run files kept by `spumoni build -k`
+//   (<ref>.bwt.heads/.bwt.len/.thr_pos[/.ssa/.esa]); -t is accepted and ignored
+//   (output is always in input order, the reference's -t 1 order).
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "classify.hpp"
+#include "reads.hpp"
+
+#define SPUMONI_VERSION "2.0.9"  // include/spumoni_main.hpp:24 (the version this build mirrors)
+
+using namespace spumoni_host;
+
+#define FORCE_LOG(func, ...)                                      \
+    do {                                                          \
+        std::fprintf(stderr, "\033[32m[%s] \033[0m", func);       \
+        std::fprintf(stderr, __VA_ARGS__);                        \
+        std::fprintf(stderr, "\n");                               \
+    } while (0)
+#define STATUS_LOG(x, ...)                                        \
+    do {                                                          \
+        std::fprintf(stderr, "\033[32m[%s] \033[0m", x);          \
+        std::fprintf(stderr, __VA_ARGS__);                        \
+        std::fprintf(stderr, " ... ");                            \
+    } while (0)
+#define DONE_LOG(x)                                               \
+    do {                                                          \
+        auto sec = std::chrono::duration<double>(x);              \
+        std::fprintf(stderr, "done.  (%.3f sec)\n", sec.count()); \
+    } while (0)
+
+static int is_file(const std::string& path) {
+    struct stat st;
+    return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+static bool ends_with(const std::string& s, const std::string& suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+static int spumoni_run_usage() {
+    std::fprintf(stderr, "spumoni run - Uses a spumoni index to compute MS/PML of patterns w.r.t. a reference.\n");
+    std::fprintf(stderr, "Usage: spumoni run [options]\n\n");
+    std::fprintf(stderr, "Options:\n");
+    std::fprintf(stderr, "\tGeneral options:\n");
+    std::fprintf(stderr, "\t%-35sprints this usage message\n", "-h, --help");
+    std::fprintf(stderr, "\t%-25s%-10snumber of helper threads (default: 1)\n\n", "-t, --threads", "[INT]");
+    std::fprintf(stderr, "\tInput/output options:\n");
+    std::fprintf(stderr, "\t%-25s%-10soutput prefix used for index\n", "-r, --ref", "[FILE]");
+    std::fprintf(stderr, "\t%-25s%-10spath to patterns file that will be used.\n", "-p, --pattern", "[FILE]");
+    std::fprintf(stderr, "\t%-25s%-10suse index to compute MSs\n", "-M, --MS", "");
+    std::fprintf(stderr, "\t%-25s%-10suse index to compute PMLs\n", "-P, --PML", "");
+    std::fprintf(stderr, "\t%-25s%-10spattern file is general text (default: FASTA)\n", "-g, --general", "");
+    std::fprintf(stderr, "\t%-25s%-10suse document array to get assignments\n", "-d, --doc-array", "");
+    std::fprintf(stderr, "\t%-25s%-10swrite out the classifications in a report file\n", "-c, --classify", "");
+    std::fprintf(stderr, "\t%-25s%-10ssize of region in bp for classification (default: 150)\n\n", "-w, --window", "[INT]");
+    std::fprintf(stderr, "\tMinimizer options:\n");
+    std::fprintf(stderr, "\t%-25s%-10sturn off minimizer digestion of reads (default: on)\n", "-n, --no-digest", "");
+    std::fprintf(stderr, "\t%-25s%-10suse alphabet-promoted minimizers\n", "-m, --minimizer-alphabet", "");
+    std::fprintf(stderr, "\t%-25s%-10suse DNA-letter based minimizers\n", "-a, --dna-minimizer", "");
+    std::fprintf(stderr, "\t%-25s%-10ssmall window size (k) for finding minimizers (default: 4)\n", "-K, --small-window", "[INT]");
+    std::fprintf(stderr, "\t%-25s%-10slarge window size (w) for finding minimizers (default: 11)\n\n", "-W, --large-window", "[INT]");
+    return 0;
+}
+
+struct CliOptions : RunOptions {
+    bool ms_requested = false, pml_requested = false;
+    int result_type = 2;  // 0 MS, 1 PML, 2 NOT_CHOSEN
+    int ref_type = 2;     // 0 FASTA, 1 MINIMIZER, 2 NOT_SET
+};
+
+static void parse_run_options(int argc, char** argv, CliOptions* opts) {
+    // option table as in the reference, including `--dna-minimizer` being wired to 't'
+    // (src/spumoni.cpp:179)
+    static struct option long_options[] = {{"help", no_argument, NULL, 'h'},
+                                           {"threads", required_argument, NULL, 't'},
+                                           {"ref", required_argument, NULL, 'r'},
+                                           {"pattern", required_argument, NULL, 'p'},
+                                           {"MS", no_argument, NULL, 'M'},
+                                           {"PML", no_argument, NULL, 'P'},
+                                           {"general-text", no_argument, NULL, 'g'},
+                                           {"doc-array", no_argument, NULL, 'd'},
+                                           {"classify", no_argument, NULL, 'c'},
+                                           {"window", required_argument, NULL, 'w'},
+                                           {"no-digest", no_argument, NULL, 'n'},
+                                           {"minimizer-alphabet", no_argument, NULL, 'm'},
+                                           {"dna-minimizer", no_argument, NULL, 't'},
+                                           {"small-window", required_argument, NULL, 'K'},
+                                           {"large-window", required_argument, NULL, 'W'},
+                                           {0, 0, 0, 0}};
+    int long_index = 0;
+    for (int c; (c = getopt_long(argc, argv, "hr:p:MPt:dcnmaK:W:w:g", long_options, &long_index)) >= 0;) {
+        switch (c) {
+            case 'h': spumoni_run_usage(); std::exit(1);
+            case 'r': opts->ref_file.assign(optarg); break;
+            case 'p': opts->pattern_file.assign(optarg); break;
+            case 'M': opts->ms_requested = true; break;
+            case 'P': opts->pml_requested = true; break;
+            case 'c': opts->write_report = true; break;
+            case 'm': opts->use_promotions = true; break;
+            case 'a': opts->use_dna_letters = true; break;
+            case 'n': opts->min_digest = false; break;
+            case 'K': opts->k = std::max(std::atoi(optarg), 1); break;
+            case 'W': opts->w = std::max(std::atoi(optarg), 1); break;
+            case 'w': opts->bin_size = std::max(std::atoi(optarg), 1); break;
+            case 'g': opts->is_general_text = true; break;
+            case 't': opts->threads = std::max(optarg ? std::atoi(optarg) : 1, 1); break;
+            case 'd': opts->use_doc = true; break;
+            default: spumoni_run_usage(); std::exit(1);
+        }
+    }
+}
+
+static void populate_types(CliOptions& o) {  // include/spumoni_main.hpp:252-265
+    if (o.ms_requested && !o.pml_requested) o.result_type = 0;
+    if (!o.ms_requested && o.pml_requested) o.result_type = 1;
+    bool is_fasta = (is_file(o.ref_file + ".fa") || is_file(o.ref_file + ".fasta") || is_file(o.ref_file + ".fna"));
+    bool is_min = is_file(o.ref_file + ".bin");
+    if (is_fasta && !is_min) o.ref_type = 0;
+    if (!is_fasta && is_min) o.ref_type = 1;
+}
+
+static void validate(const CliOptions& o) {  // include/spumoni_main.hpp:267-329
+    if (o.ref_file == "" || o.pattern_file == "") fatal_warning("Both a reference file (-r) and pattern file (-p) must be provided.");
+    if (o.result_type == 2) fatal_warning("An output type with -M or -P must be specified, only one can be used at a time.");
+    std::string extension = o.use_promotions ? ".bin" : ".fa";
+    if (!is_file(o.ref_file + extension))
+        fatal_error("The following path is not valid: %s (remember to only specify output prefix)", (o.ref_file + extension).data());
+    if (!is_file(o.pattern_file)) fatal_error("The following path is not valid: %s", o.pattern_file.data());
+    if (!o.is_general_text && o.ref_type == 2)
+        fatal_error("Reference file is an unrecognized type. It needs to be a\n"
+                    "       FASTA file or binary file produced by spumoni build.");
+    if (!o.is_general_text && !ends_with(o.pattern_file, ".fa") && !ends_with(o.pattern_file, ".fasta") &&
+        !ends_with(o.pattern_file, ".fna"))
+        fatal_error("The pattern file provided does not appear to be a FASTA\n"
+                    "       file, please convert to FASTA and re-run.");
+    if (o.is_general_text && o.min_digest) fatal_warning("For general-text querying, minimizer digestion must be turned off with -n.");
+    if (o.is_general_text && o.threads > 1) fatal_warning("For general-text querying, multi-threading is not available.");
+    if (o.is_general_text && o.write_report) fatal_warning("For general-text querying, classification is not available.");
+    if (o.use_doc && !is_file(o.ref_file + extension + ".doc"))
+        fatal_warning("document array file (%s) is not present, so it cannot be used.", (o.ref_file + extension + ".doc").data());
+    // index: the reference checks <ref>.thrbv.ms / .thrbv.spumoni; this build reads the raw run files
+    const std::string base = o.ref_file + extension;
+    const bool have_raw = is_file(base + ".bwt.heads") && is_file(base + ".bwt.len") && is_file(base + ".thr_pos") &&
+                          (o.result_type != 0 || (is_file(base + ".ssa") && is_file(base + ".esa")));
+    if (!have_raw) {
+        const std::string ser = base + (o.result_type == 0 ? ".thrbv.ms" : ".thrbv.spumoni");
+        if (is_file(ser))
+            fatal_error("found %s but not the raw run files it was built from\n"
+                        "       (.bwt.heads/.bwt.len/.thr_pos[/.ssa/.esa]): this build reads those (spumoni build -k).", ser.data());
+        fatal_warning("The index required for this computation is not available, please use spumoni build.");
+    }
+    if (o.k > 4) fatal_warning("small window size (k) cannot be larger than 4 characters.");
+    if (o.w < o.k) fatal_warning("large window size (w) should be larger than the small window size (k)");
+    if (o.min_digest) {
+        if (o.use_promotions && o.use_dna_letters) fatal_error("Only one type of minimizer can be specified from either -m or -a.");
+        if (!o.use_promotions && !o.use_dna_letters) fatal_error("A minimizer type must be specified using -m or -a.");
+    } else {
+        if (o.use_promotions || o.use_dna_letters)
+            fatal_error("A minimizer type should not be specified if intending not to use minimizer digestion.");
+    }
+    if (o.bin_size < 50 || o.bin_size > 400)
+        fatal_warning("the bin size used is not optimal. Re-run using a value between 50 and 400.");
+}
+
+static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_main (:1305-1382)
+    const char* tag = o.ms ? "compute_ms" : "compute_pml";
+    IndexSet set;
+    STATUS_LOG(o.ms ? "ms_construct" : "pml_construct", o.ms ? "loading the MS index" : "loading the PML index");
+    auto start_time = std::chrono::system_clock::now();
+    set.load(o);
+    DONE_LOG((std::chrono::system_clock::now() - start_time));
+    std::cout << std::endl;
+    if (o.use_promotions)
+        FORCE_LOG(tag, "input reads will digested using promoted minimizer alphabet (k=%d, w=%d)", (int)o.k, (int)o.w);
+    else if (o.use_dna_letters)
+        FORCE_LOG(tag, "input reads will digested using DNA minimizer alphabet (k=%d, w=%d)", (int)o.k, (int)o.w);
+    else
+        FORCE_LOG(tag, "input reads will be used directly, no minimizer digestion");
+    start_time = std::chrono::system_clock::now();
+    STATUS_LOG(tag, o.ms ? "processing the reads" : "processing the patterns");
+    size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o);
+    DONE_LOG((std::chrono::system_clock::now() - start_time));
+    FORCE_LOG(tag, "finished processing %d reads. results are saved in *.%s file.", (int)num_reads,
+              o.ms ? "lengths" : "pseudo_lengths");
+    std::cout << std::endl;
+    return 0;
+}
+
+static int run_main(int argc, char** argv) {
+    if (argc == 1) return spumoni_run_usage();
+    CliOptions o;
+    parse_run_options(argc, argv, &o);
+    populate_types(o);
+    validate(o);
+    o.ref_file += o.use_promotions ? ".bin" : ".fa";  // spumoni.cpp:744-747
+    o.ms = (o.result_type == 0);
+    if (const char* g = std::getenv("SPUMONI_GPUS")) {
+        o.devices.clear();
+        std::stringstream ss(g);
+        std::string tok;
+        while (std::getline(ss, tok, ','))
+            if (!tok.empty()) o.devices.push_back(std::atoi(tok.c_str()));
+        if (o.devices.empty()) o.devices.push_back(0);
+    }
+    if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
+    return run_spumoni(o);
+}
+
+// debugging aid used by the CPU tests: dump the reads the batch segmentation yields
+static int dump_reads_main(int argc, char** argv) {
+    if (argc < 2) return 1;
+    ReadFile in(argv[1]);
+    std::vector<ParsedRead> batch;
+    size_t nb = 0;
+    while (in.next_batch(1000, batch)) {
+        std::printf("#batch %zu\n", nb++);
+        for (auto& rd : batch) std::printf("%s\t%s\n", rd.id.c_str(), rd.seq.c_str());
+    }
+    return 0;
+}
+
+static int spumoni_usage() {
+    std::fprintf(stderr, "SPUMONI has different sub-commands to run which can used as follows:\n");
+    std::fprintf(stderr, "Usage: spumoni <command> [options]\n\n");
+    std::fprintf(stderr, "Commands:\n");
+    std::fprintf(stderr, "\tbuild\tbuilds the index needed to compute MS or PMLs for a specified reference.\n");
+    std::fprintf(stderr, "\trun\tcomputes MSs or PMLs for patterns against already built SPUMONI index.\n\n");
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2 && std::strcmp(argv[1], "dump-reads") == 0) return dump_reads_main(argc - 1, argv + 1);
+    std::fprintf(stderr, "\n\033[1m\033[31mSPUMONI version: %s \033[0m\n\n", SPUMONI_VERSION);
+    if (argc > 1) {
+        if (std::strcmp(argv[1], "build") == 0)
+            fatal_error("`spumoni build` is not part of the MI355X run-path package: build the index with the\n"
+                        "       reference (keep the raw files with -k) and query it here.");
+        if (std::strcmp(argv[1], "run") == 0) return run_main(argc - 1, argv + 1);
+    }
+    return spumoni_usage();
+}

@@ -1,0 +1,114 @@
+"""-m gpu: the HIP-backed `spumoni run` binary against the oracle harness (oracle/orc_run):
+every output file must be byte-identical."""
+import filecmp
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from spumoni_amd import synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_BIN = os.path.join(ROOT, "spumoni_amd", "bin", "spumoni")
+ORC_RUN = os.path.join(ROOT, "oracle", "orc_run")
+
+
+def _write_fasta(path, seqs, offs, rng, fastq=False):
+    with open(path, "w") as f:
+        for q in range(offs.size - 1):
+            s = seqs[offs[q] : offs[q + 1]].tobytes().decode("latin-1")
+            if not s:
+                continue
+            if rng.random() < 0.3:
+                s = s.lower()
+            name = f"read_{q}" + (" some description" if q % 5 == 0 else "")
+            if fastq:
+                f.write(f"@{name}\n{s}\n+\n{'I' * len(s)}\n")
+            else:
+                cut = int(rng.integers(1, len(s) + 1))
+                f.write(f">{name}\n{s[:cut]}\n" + (f"{s[cut:]}\n" if cut < len(s) else ""))
+
+
+def _setup(tmp_path, seed, letters, n=6000, nreads=300):
+    raw, text = cases.real_case(seed, n, letters, ndocs=4)
+    ref = str(tmp_path / "ref")
+    open(ref + ".fa", "w").write(">dummy\n")  # run's validate() insists on <ref>.fa existing
+    prefix = ref + ".fa"
+    raw.write_raw_files(prefix)
+    text.tofile(prefix + ".rawtext")
+    # side files: .doc, .pmlnulldb / .msnulldb (sdsl framing written by our host writers via a helper)
+    from tests.sdsl_files import write_doc_array, write_null_db
+
+    write_doc_array(prefix + ".doc", raw.doc_start.numpy(), raw.doc_end.numpy())
+    write_null_db(prefix + ".pmlnulldb", 4.0, [1, 2, 3, 4, 4, 4, 4, 4])
+    write_null_db(prefix + ".msnulldb", 9.0, [5, 9, 9, 9, 9, 9])
+    rng = np.random.default_rng(seed)
+    seqs, offs = cases.reads_mixed(rng, text, letters, nreads, 400, [ord("N")])
+    return ref, prefix, seqs, offs, rng
+
+
+def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, fastq=False):
+    a_dir, b_dir = tmp_path / "gpu", tmp_path / "orc"
+    for d in (a_dir, b_dir):
+        shutil.rmtree(d, ignore_errors=True)
+        d.mkdir()
+    _write_fasta(a_dir / reads_name, seqs, offs, np.random.default_rng(77), fastq)
+    shutil.copy(a_dir / reads_name, b_dir / reads_name)
+    env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext")
+    cmd = [HOST_BIN, "run", "-r", ref, "-p", str(a_dir / reads_name), "-n", mode] + flags
+    r = subprocess.run(cmd, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"finished processing" in r.stderr
+    doc = "1" if "-d" in flags else "0"
+    rep = "1" if "-c" in flags else "0"
+    bw = flags[flags.index("-w") + 1] if "-w" in flags else "150"
+    o = subprocess.run([ORC_RUN, prefix, str(b_dir / reads_name), mode[1], doc, rep, bw, "n", prefix + ".rawtext"],
+                       capture_output=True)
+    assert o.returncode == 0, o.stderr.decode()
+    exts = [".pseudo_lengths"] if mode == "-P" else [".lengths", ".pointers"]
+    if doc == "1":
+        exts.append(".doc_numbers")
+    if rep == "1":
+        exts.append(".report")
+    for e in exts:
+        fa, fb = str(a_dir / reads_name) + e, str(b_dir / reads_name) + e
+        assert os.path.getsize(fb) > 0
+        assert filecmp.cmp(fa, fb, shallow=False), e
+    return r
+
+
+@pytest.fixture(scope="module")
+def built():
+    assert torch.cuda.is_available()
+    assert os.path.exists(HOST_BIN) and os.path.exists(ORC_RUN), "run __graft_entry__.build() first"
+
+
+def test_cli_pml_report_doc(built, tmp_path):
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 41, list(b"ACGT"))
+    r = _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    assert b"loading the PML index" in r.stderr and b"no minimizer digestion" in r.stderr
+
+
+def test_cli_ms_report_doc(built, tmp_path):
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 42, list(b"ACGT"))
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "60"], "-M")
+
+
+def test_cli_fastq_content_in_fa_named_file(built, tmp_path):
+    # validate() insists on a .fa name even for FASTQ content (include/spumoni_main.hpp:288-290)
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 43, list(b"ACGT"), nreads=120)
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c"], "-P", fastq=True)
+
+
+def test_cli_validation_messages(built, tmp_path):
+    r = subprocess.run([HOST_BIN, "run", "-r", str(tmp_path / "nope"), "-p", str(tmp_path / "x.fa"), "-P", "-n"],
+                       capture_output=True)
+    assert r.returncode == 1 and b"The following path is not valid" in r.stderr
+    r = subprocess.run([HOST_BIN, "run", "-r", "a", "-p", "b"], capture_output=True)
+    assert r.returncode == 1 and b"An output type with -M or -P must be specified" in r.stderr
