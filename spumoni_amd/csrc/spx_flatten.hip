@@ -349,10 +349,11 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     (void)hipFree(LFs.p);
     LFs.p = nullptr;
 
-    // directory block size: about half a run of a typical letter per block, so that for
-    // most jumps the block's fat entry already IS the successor run
-    uint32_t bshift = 2;
-    while ((2u << bshift) <= nletters && bshift < 16) bshift++;
+    // directory block size: the smallest power of two >= nletters / 3 runs, i.e. a fat table of
+    // at most ~96 B per run (2 runs per block for DNA, 128 for the 253-letter minimizer
+    // alphabet): small enough that the block's fat entry usually IS the successor run
+    uint32_t bshift = 0;
+    while ((3u << bshift) < nletters && bshift < 16) bshift++;
     const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
     const uint64_t nfat = (uint64_t)nletters * nblk;
     DevBuf cnt;

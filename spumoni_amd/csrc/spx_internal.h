@@ -43,6 +43,7 @@ struct BatchArgs {
     uint64_t bin_width;
     uint64_t max_value_thr;
     WalkCounters* counters;
+    uint32_t lanes_per_wave;  // active lanes per wavefront (64 unless the batch is small)
 };
 
 }  // namespace spx

@@ -62,7 +62,7 @@ template <int MODE, bool DOC>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
     constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
     __shared__ LetterInfo s_let[256];
-    for (int t = threadIdx.x; t < 256; t += WALK_TPB) s_let[t] = ix.letters[t];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) s_let[t] = ix.letters[t];
     __syncthreads();
 
     const char* const rows_b = reinterpret_cast<const char*>(ix.rows);
@@ -73,10 +73,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     const char* const off_b = reinterpret_cast<const char*>(b.offs);
     const uint32_t R = ix.r;
     const bool want_class = (MODE == SPX_MODE_PML) && b.out_class != nullptr;
-    const uint64_t nlanes = (uint64_t)gridDim.x * WALK_TPB;
+    // lanes_per_wave < 64 spreads a small batch over more wavefronts (see launch_lanes)
+    const uint32_t lpw = b.lanes_per_wave;
+    const uint64_t nlanes = (((uint64_t)gridDim.x * blockDim.x) >> 6) * lpw;
 
     uint32_t ph = P_READ;
-    uint64_t rd = (uint64_t)blockIdx.x * WALK_TPB + threadIdx.x;
+    uint64_t rd = ((((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * lpw) + (threadIdx.x & 63);
     uint64_t base = 0;
     uint32_t m = 0, x = 0;  // x = characters still to search; next one is index x-1
     // landed position: run k, offset off; fields of row k
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // statistics
     uint32_t n_steps = 0, n_jumps = 0, n_pred = 0, n_rows = 0, n_dir = 0, n_err = 0;
 
-    if (rd >= b.nreads) ph = P_DONE;
+    if (rd >= b.nreads || (threadIdx.x & 63) >= lpw) ph = P_DONE;
 
     while (ph != P_DONE) {
         // ---- the one gather of this iteration -------------------------------
@@ -504,16 +506,34 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
         SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
         ix->num_cus = prop.multiProcessorCount;
     }
+    // Occupancy target: 12 waves per CU.  Measured on C3 (tools/sweep.py): 262 / 478 / 612 /
+    // 597 / 565 M reads/s at 4 / 8 / 12 / 16 / 20 waves per CU -- past ~200 k lanes more
+    // chains only add queueing in front of the same HBM line-fill rate.
     int occ = ix->occ_blocks[slot];
-    if (ix->waves_per_cu > 0) {
-        int want = ix->waves_per_cu / (WALK_TPB / 64);
-        if (want >= 1 && want < occ) occ = want;
-    }
+    const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : 12;
+    int want = target_waves / (WALK_TPB / 64);
+    if (want < 1) want = 1;
+    if (want < occ) occ = want;
+    unsigned tpb = WALK_TPB;
     uint64_t grid = (uint64_t)occ * ix->num_cus;
-    uint64_t need = (args.nreads + WALK_TPB - 1) / WALK_TPB;
-    if (need < grid) grid = need;
+    const uint64_t need = (args.nreads + WALK_TPB - 1) / WALK_TPB;
+    BatchArgs a = args;
+    a.lanes_per_wave = 64;
+    if (need < grid) {
+        // Fewer reads than lanes (long-read batches): the walk of a read is one dependent
+        // chain, so the batch is latency-bound.  Spread it: 64-thread blocks, one or more per
+        // SIMD, and only as many active lanes per wavefront as needed -- a wavefront whose few
+        // lanes sit in the same phase issues a fraction of the instructions per iteration.
+        tpb = 64;
+        const uint64_t waves = (uint64_t)ix->num_cus * 4;  // one wavefront per SIMD
+        uint64_t lpw = (args.nreads + waves - 1) / waves;
+        if (lpw < 1) lpw = 1;
+        if (lpw > 64) lpw = 64;
+        a.lanes_per_wave = (uint32_t)lpw;
+        grid = (args.nreads + lpw - 1) / lpw;
+    }
     if (grid == 0) grid = 1;
-    k_walk_lanes<MODE, DOC><<<(unsigned)grid, WALK_TPB, 0, stream>>>(ix->view, args);
+    k_walk_lanes<MODE, DOC><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }

@@ -1,0 +1,102 @@
+"""-m gpu: BASELINE configs at (or near) their full sizes.  The oracle checks a sample bit for
+bit; the whole batch is checked through size-independent properties of the walk:
+ * partition invariance  -- a read's result does not depend on which batch / lane it ran in;
+ * suffix property       -- the walk starts at the right end of a read, so PML(read[j:]) ==
+                            PML(read)[j:] for every j (same for MS pointers);
+ * classification        -- reads sampled from the text are FOUND, reversed ones are not.
+"""
+import numpy as np
+import pytest
+import torch
+
+from spumoni_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pml_dev(ix, seqs_t, offs_t, classify=None):
+    d_seqs = capi.pad_seqs(seqs_t)
+    n = seqs_t.numel()
+    d_len = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+    d_cls = torch.empty((offs_t.numel() - 1, 2), dtype=torch.int64, device="cuda") if classify else None
+    bw, thr = classify if classify else (0, 0)
+    ix.query_device(capi.SPX_MODE_PML, d_seqs, offs_t, n, d_lengths=d_len, d_class=d_cls, bin_width=bw, max_value_thr=thr)
+    torch.cuda.synchronize()
+    ix.last_stats()  # raises if the walk flagged an inconsistency
+    return d_len[:n], d_cls
+
+
+def test_config2_five_strain_ecoli_1m_reads(oracle_mod):
+    """BASELINE config[1]: 5-strain E. coli pangenome (+revcomp, 46.4 Mbp), 1M x 200 bp, PML."""
+    base = synth.random_genome(4_641_652, seed=1)
+    genomes = [base] + [synth.mutate(base, seed=s) for s in (2, 3, 4, 5)]
+    text, doc_lengths = synth.pangenome_text(genomes)
+    raw = synth.index_from_text(torch.from_numpy(text).cuda(), doc_lengths=doc_lengths, with_samples=False)
+    assert raw.n == text.size + 1
+    nreads, m = 1_000_000, 200
+    seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
+    ix = capi.Index.from_raw(raw, 0)
+    d_seqs, d_offs = torch.from_numpy(seqs).cuda(), torch.from_numpy(offs).cuda()
+    full, cls = _pml_dev(ix, d_seqs, d_offs, classify=(150, 7))
+    # (1) oracle on a sample, bit-exact
+    ns = 20_000
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs[: ns * m], offs[: ns + 1])
+    assert np.array_equal(full[: ns * m].cpu().numpy().view(np.uint32), want)
+    # (2) partition invariance: second half of the reads as its own batch
+    h = nreads // 2
+    half, _ = _pml_dev(ix, d_seqs[h * m :], d_offs[h:] - d_offs[h])
+    assert torch.equal(half, full[h * m :])
+    # (3) suffix property on 100k reads cut at random positions
+    rng = np.random.default_rng(0)
+    cut = torch.from_numpy(rng.integers(1, m, size=100_000)).cuda()
+    idx = torch.arange(100_000, device="cuda")
+    lens = m - cut
+    so = torch.zeros(100_001, dtype=torch.int64, device="cuda")
+    so[1:] = torch.cumsum(lens, 0)
+    pos = torch.arange(int(so[-1]), device="cuda")
+    rid = torch.searchsorted(so, pos, right=True) - 1
+    src = rid * m + cut[rid] + (pos - so[rid])
+    sfx, _ = _pml_dev(ix, d_seqs[src], so)
+    assert torch.equal(sfx, full[src])
+    # (4) classification separates sampled (FOUND) from reversed (NOT_PRESENT) reads
+    c32 = cls.view(torch.int32).view(-1, 4)
+    found = (2 * c32[:, 2] > c32[:, 2] + c32[:, 3]).float().mean().item()
+    assert 0.45 < found < 0.55
+    st = ix.last_stats()
+    assert st["steps"] == lens.sum().item()
+
+
+def test_config3_shape_properties(oracle_mod):
+    """BASELINE config[2] shape at r = 2^25 (the bench itself gates r = 2^28 against the oracle)."""
+    raw = synth.statistical_rlbwt(1 << 25, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 2_000_000, 44, seed=13)
+    ix = capi.Index.from_raw(raw, 0)
+    full, _ = _pml_dev(ix, seqs, offs)
+    ns = 50_000
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs[: ns * 44].cpu().numpy(), offs[: ns + 1].cpu().numpy())
+    assert np.array_equal(full[: ns * 44].cpu().numpy().view(np.uint32), want)
+    # partition invariance with ragged split
+    k = 777_777
+    a, _ = _pml_dev(ix, seqs[: k * 44], offs[: k + 1])
+    b, _ = _pml_dev(ix, seqs[k * 44 :], offs[k:] - offs[k])
+    assert torch.equal(torch.cat([a, b]), full)
+
+
+def test_config5_long_reads(oracle_mod):
+    """BASELINE config[4] shape: few long reads (latency-bound small-batch launch geometry)."""
+    raw = synth.statistical_rlbwt(1 << 22, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 700, 2200, seed=16)
+    ix = capi.Index.from_raw(raw, 0)
+    full, _ = _pml_dev(ix, seqs, offs, classify=(150, 5))
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs.cpu().numpy(), offs.cpu().numpy())
+    assert np.array_equal(full.cpu().numpy().view(np.uint32), want)
+    # a read longer than 65535 characters takes the unstaged output path
+    long_seqs, long_offs = synth.simulate_reads(raw, 3, 70_000, seed=17, positive_fraction=0.0)
+    h = raw.heads[torch.randint(1, raw.r, (40_000,), device="cuda")]  # make part of one read match-rich
+    long_seqs[100:40_100] = h
+    got, _ = _pml_dev(ix, long_seqs, long_offs)
+    want = orc.pml(long_seqs.cpu().numpy(), long_offs.cpu().numpy())
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want)

@@ -1,0 +1,60 @@
+"""Throughput sweep of the walk kernel over workloads / occupancies (run on the GPU box)."""
+import os, sys, time, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spumoni_amd import capi, synth
+
+def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3):
+    ix = capi.Index.from_raw(raw, 0)
+    if waves: ix.set_option("waves_per_cu", waves)
+    total = int(seqs.numel()); nreads = offs.numel() - 1
+    d_seqs = capi.pad_seqs(seqs)
+    d_len = torch.empty(total, dtype=torch.int32, device="cuda") if mode == capi.SPX_MODE_PML else None
+    d_ptr = torch.empty(total, dtype=torch.int64, device="cuda") if mode == capi.SPX_MODE_MS else None
+    d_doc = torch.empty(total, dtype=torch.int32, device="cuda") if docs else None
+    d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda") if mode == capi.SPX_MODE_PML else None
+    ms = []
+    for _ in range(reps + 1):
+        ix.query_device(mode, d_seqs, offs, total, d_lengths=d_len, d_pointers=d_ptr, d_docs=d_doc, d_class=d_cls,
+                        bin_width=150, max_value_thr=5)
+        st = ix.last_stats(); ms.append(st["kernel_ms"])
+    k = float(np.median(ms[1:]))
+    f_mis = st["jumps"] / st["steps"]; f_pred = st["pred_jumps"] / st["steps"]
+    out_b = 4 if mode == capi.SPX_MODE_PML else 8
+    bstep = 64 * (1 + 2 * f_mis + f_pred) + 1 + out_b + (4 if docs else 0)
+    print(f"{tag:42s} r={raw.r:>11d} n/r={raw.n/raw.r:6.1f} waves={waves or 'max':>3} kernel {k:8.2f} ms  "
+          f"{st['steps']/k/1e6:7.2f} Gsteps/s  {nreads/k/1e3:8.1f} Mreads/s  f_mis {f_mis:.3f} rows/step {st['row_loads']/st['steps']:.2f} "
+          f"dir/step {st['dir_loads']/st['steps']:.2f}  roofline {bstep*st['steps']/k/1e6/8000:.3f}  idx {ix.device_bytes/2**30:.1f} GiB", flush=True)
+    ix.close()
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "occ"):
+    raw = synth.statistical_rlbwt(1 << 28, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
+    for w in (4, 8, 12, 16, 20):
+        run("C3 minimizer sigma=253 m=44", raw, seqs, offs, waves=w)
+    del raw, seqs, offs
+if which in ("all", "dna"):
+    raw = synth.statistical_rlbwt(1 << 27, 4, 60.0, seed=4, device="cuda", letters=b"ACGT")
+    seqs, offs = synth.simulate_reads(raw, 4_000_000, 200, seed=14)
+    run("C3 DNA sigma=4 mean_run=60 m=200", raw, seqs, offs)
+    del raw, seqs, offs
+if which in ("all", "ms"):
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=5, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
+    seqs, offs = synth.simulate_reads(raw, 5_000_000, 55, seed=15)
+    run("C4 MS + doc sigma=253 m=55", raw, seqs, offs, mode=capi.SPX_MODE_MS, docs=True)
+    run("C4-shaped PML + doc", raw, seqs, offs, docs=True)
+    del raw, seqs, offs
+if which in ("all", "long"):
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 50_000, 2200, seed=16)
+    run("C5 long reads 50k x 2200", raw, seqs, offs)
+    seqs, offs = synth.simulate_reads(raw, 6_250, 2200, seed=17)
+    run("C5 per-GPU share 6250 x 2200", raw, seqs, offs)
+    del raw, seqs, offs
+if which in ("big",):
+    t0 = time.time()
+    raw = synth.statistical_rlbwt(1_000_000_000, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
+    torch.cuda.synchronize(); print("gen", time.time() - t0, flush=True)
+    run("C3 r=1e9 minimizer sigma=253 m=44", raw, seqs, offs)
