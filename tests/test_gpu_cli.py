@@ -112,3 +112,39 @@ def test_cli_validation_messages(built, tmp_path):
     assert r.returncode == 1 and b"The following path is not valid" in r.stderr
     r = subprocess.run([HOST_BIN, "run", "-r", "a", "-p", "b"], capture_output=True)
     assert r.returncode == 1 and b"An output type with -M or -P must be specified" in r.stderr
+
+
+def test_pml_t_ms_t_mirror_per_read_calls(built, tmp_path, oracle_mod):
+    """host/spumoni_index.hpp: the reference's pml_t / ms_t interface, one call per read."""
+    shim = HOST_BIN.replace("bin/spumoni", "bin/shim_check")
+    raw, text = cases.real_case(44, 3000, list(b"ACGT"), ndocs=3)
+    prefix = str(tmp_path / "idx")
+    raw.write_raw_files(prefix)
+    text.tofile(prefix + ".rawtext")
+    from tests.sdsl_files import write_doc_array
+
+    write_doc_array(prefix + ".doc", raw.doc_start.numpy(), raw.doc_end.numpy())
+    rng = np.random.default_rng(4)
+    seqs, offs = cases.reads_mixed(rng, text, list(b"ACGT"), 40, 80, [ord("N")])
+    reads = [seqs[offs[q] : offs[q + 1]].tobytes().decode() for q in range(offs.size - 1)]
+    reads = [r for r in reads if r]
+    (tmp_path / "reads.txt").write_text("\n".join(reads) + "\n")
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    s2 = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    o2 = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    pml, pdocs = orc.pml(s2, o2, want_docs=True)
+    ms = orc.ms(s2, o2, want_docs=True, text=text)
+    for mode in ("P", "M"):
+        out = subprocess.run([shim, prefix, str(tmp_path / "reads.txt"), mode, "1"], capture_output=True)
+        assert out.returncode == 0, out.stderr.decode()
+        lines = out.stdout.decode().splitlines()
+        assert lines[0] == f"stats {raw.n} {raw.r}"
+        got = {"L": [], "P": [], "D": []}
+        for ln in lines[1:]:
+            tag, *vals = ln.split()
+            got[tag].extend(int(v) for v in vals)
+        if mode == "P":
+            assert got["L"] == pml.tolist() and got["D"] == pdocs.tolist()
+        else:
+            assert got["L"] == ms["lengths"].tolist() and got["P"] == ms["pointers"].tolist()
+            assert got["D"] == ms["docs"].tolist()
