@@ -109,6 +109,8 @@ void spx_index_free(spx_index* ix) {
     if (ix->letters) (void)hipFree(ix->letters);
     if (ix->text) (void)hipFree(ix->text);
     if (ix->counters) (void)hipFree(ix->counters);
+    for (auto& sc : ix->scratch)
+        if (sc.p) (void)hipFree(sc.p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     delete ix;
@@ -369,24 +371,36 @@ int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t
     int rc = check_query(ix, mode, seqs, offsets, out_lengths, out_pointers, out_docs, out_class,
                          bin_width);
     if (rc != SPX_OK) return rc;
+    std::lock_guard<std::mutex> hg(ix->host_mu);  // one host-buffer query at a time per index
     SPX_HIP(hipSetDevice(ix->device));
     const uint64_t total = nreads ? offsets[nreads] : 0;
-    struct Tmp {
-        void* p = nullptr;
-        ~Tmp() {
-            if (p) (void)hipFree(p);
+    // grow-only device scratch owned by the index (no hipMalloc/hipFree per call)
+    struct Ref {
+        void* p;
+    } dseq{nullptr}, doff{nullptr}, dlen{nullptr}, dptr{nullptr}, ddoc{nullptr}, dcls{nullptr};
+    auto ensure = [&](int slot, size_t bytes, void** out) -> int {
+        spx_index::Scratch& sc = ix->scratch[slot];
+        if (sc.cap < bytes) {
+            if (sc.p) (void)hipFree(sc.p);
+            sc.p = nullptr;
+            sc.cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            SPX_HIP(hipMalloc(&sc.p, want));
+            sc.cap = want;
         }
-    } dseq, doff, dlen, dptr, ddoc, dcls;
+        *out = sc.p;
+        return SPX_OK;
+    };
     const uint64_t padded = ((total + 3) / 4) * 4 + 32;
-    SPX_HIP(hipMalloc(&dseq.p, padded));
-    SPX_HIP(hipMemset(dseq.p, 0, padded));
+    if ((rc = ensure(0, padded, &dseq.p)) != SPX_OK) return rc;
     SPX_HIP(hipMemcpy(dseq.p, seqs, total, hipMemcpyHostToDevice));
-    SPX_HIP(hipMalloc(&doff.p, (nreads + 1) * 8));
+    SPX_HIP(hipMemset((char*)dseq.p + total, 0, padded - total));
+    if ((rc = ensure(1, (nreads + 1) * 8, &doff.p)) != SPX_OK) return rc;
     SPX_HIP(hipMemcpy(doff.p, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
-    if (out_lengths) SPX_HIP(hipMalloc(&dlen.p, (total + 1) * 4));
-    if (out_pointers) SPX_HIP(hipMalloc(&dptr.p, (total + 1) * 8));
-    if (out_docs) SPX_HIP(hipMalloc(&ddoc.p, (total + 1) * 4));
-    if (out_class) SPX_HIP(hipMalloc(&dcls.p, (nreads + 1) * sizeof(spx_class)));
+    if (out_lengths && (rc = ensure(2, (total + 1) * 4, &dlen.p)) != SPX_OK) return rc;
+    if (out_pointers && (rc = ensure(3, (total + 1) * 8, &dptr.p)) != SPX_OK) return rc;
+    if (out_docs && (rc = ensure(4, (total + 1) * 4, &ddoc.p)) != SPX_OK) return rc;
+    if (out_class && (rc = ensure(5, (nreads + 1) * sizeof(spx_class), &dcls.p)) != SPX_OK) return rc;
     rc = spx_query_batch_device(ix, mode, (const uint8_t*)dseq.p, (const uint64_t*)doff.p, nreads,
                                 total, (uint32_t*)dlen.p, (uint64_t*)dptr.p, (uint32_t*)ddoc.p,
                                 (spx_class*)dcls.p, bin_width, max_value_thr, nullptr);

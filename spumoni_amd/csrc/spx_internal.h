@@ -73,7 +73,12 @@ struct spx_index {
     int waves_per_cu = 0; // 0 = default occupancy target
     int occ_blocks[4] = {0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant
     int num_cus = 0;
-    std::mutex mu;
+    std::mutex mu;       // device-buffer queries / options
+    std::mutex host_mu;  // host-buffer queries (own the scratch below)
+    struct Scratch {
+        void* p = nullptr;
+        size_t cap = 0;
+    } scratch[6];
 };
 
 namespace spx {

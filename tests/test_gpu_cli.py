@@ -148,3 +148,14 @@ def test_pml_t_ms_t_mirror_per_read_calls(built, tmp_path, oracle_mod):
         else:
             assert got["L"] == ms["lengths"].tolist() and got["P"] == ms["pointers"].tolist()
             assert got["D"] == ms["docs"].tolist()
+
+
+def test_cli_two_device_slots_same_output(built, tmp_path):
+    """SPUMONI_GPUS=0,0: two index replicas + two host threads + sharded super-batches must give
+    byte-identical files (the multi-GPU host path, exercised on one GPU)."""
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 45, list(b"ACGT"), nreads=400)
+    os.environ["SPUMONI_GPUS"] = "0,0"
+    try:
+        _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d"], "-P")
+    finally:
+        del os.environ["SPUMONI_GPUS"]
