@@ -124,7 +124,8 @@ int spx_query_batch(spx_index *ix, int mode, const uint8_t *seqs, const uint64_t
  * is enqueued on `stream` (a hipStream_t passed as void*, NULL = default
  * stream) and the call returns without synchronising.  d_seqs must be 16-byte
  * aligned and readable for round_up(total_chars, 4) + 32 bytes (the walk reads
- * characters in aligned 32-byte windows).                                    */
+ * characters in aligned 32-byte windows); output buffers must be 16-byte
+ * aligned (results are written as 16-byte vectors).                          */
 int spx_query_batch_device(spx_index *ix, int mode, const uint8_t *d_seqs,
                            const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
                            uint32_t *d_out_lengths, uint64_t *d_out_pointers,

@@ -102,6 +102,8 @@ void spx_index_free(spx_index* ix) {
     if (ix->fat) (void)hipFree(ix->fat);
     if (ix->dirdocs) (void)hipFree(ix->dirdocs);
     if (ix->rundocs) (void)hipFree(ix->rundocs);
+    if (ix->fat_samples) (void)hipFree(ix->fat_samples);
+    if (ix->fat_docs) (void)hipFree(ix->fat_docs);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);
     if (ix->samples) (void)hipFree(ix->samples);
     if (ix->dirrows) (void)hipFree(ix->dirrows);
@@ -330,6 +332,10 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     if (rc != SPX_OK) return rc;
     if (((uintptr_t)d_seqs & 15) != 0) {
         set_error("d_seqs must be 16-byte aligned (and readable for round_up(total_chars, 4) + 32 bytes)");
+        return SPX_E_ARG;
+    }
+    if ((((uintptr_t)d_out_lengths | (uintptr_t)d_out_pointers | (uintptr_t)d_out_docs) & 15) != 0) {
+        set_error("output buffers must be 16-byte aligned (results are written as 16-byte vectors)");
         return SPX_E_ARG;
     }
     std::lock_guard<std::mutex> g(ix->mu);

@@ -205,6 +205,16 @@ __global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, uint64_t
     if (i < total) fat[i] = dirrows[cnt[i]];
 }
 
+// side data of every fat slot: the samples / doc ids of the directory position it copies
+__global__ void k_fill_fat_aux(const uint32_t* cnt, const SamplePair* samples, const uint32_t* dirdocs,
+                               uint64_t total, SamplePair* fat_samples, uint32_t* fat_docs) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t j = cnt[i];
+    if (fat_samples) fat_samples[i] = samples[j];
+    if (fat_docs) fat_docs[i] = dirdocs[j];
+}
+
 __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i < r) q_alloc[i + 1] = Qall[i];
@@ -374,10 +384,18 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, ix->samples,
                                                    ix->ss_by_run);
         SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8;
+        SPX_HIP(hipMalloc((void**)&ix->fat_samples, (nfat + 2) * sizeof(SamplePair)));
+        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8 + (nfat + 2) * sizeof(SamplePair);
         ix->has_samples = true;
     }
     ix->has_docs = docs;
+    if (docs) {
+        SPX_HIP(hipMalloc((void**)&ix->fat_docs, (nfat + 2) * 4));
+        bytes += (nfat + 2) * 4;
+    }
+    if (ix->fat_samples || ix->fat_docs)
+        k_fill_fat_aux<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->samples, ix->dirdocs, nfat,
+                                                       ix->fat_samples, ix->fat_docs);
     if (docs) {
         SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
@@ -403,6 +421,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.ss_by_run = ix->ss_by_run;
     v.dirdocs = ix->dirdocs;
     v.rundocs = ix->rundocs;
+    v.fat_samples = ix->fat_samples;
+    v.fat_docs = ix->fat_docs;
     v.letters = ix->letters;
     v.text = nullptr;
     v.n_text = 0;

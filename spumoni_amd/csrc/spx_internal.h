@@ -60,6 +60,8 @@ struct spx_index {
     uint64_t* ss_by_run = nullptr;
     uint32_t* dirdocs = nullptr;
     uint32_t* rundocs = nullptr;
+    spx::SamplePair* fat_samples = nullptr;
+    uint32_t* fat_docs = nullptr;
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;
     uint64_t n_text = 0;

@@ -122,6 +122,8 @@ struct DevIndex {
     const uint64_t* ss_by_run;  // samples_start by run index (+ pad) or nullptr
     const uint32_t* dirdocs;    // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16, or nullptr
     const uint32_t* rundocs;    // by run index k: docS[k] | docE[k] << 16, or nullptr
+    const SamplePair* fat_samples;  // samples[] entry of every fat slot (MS) or nullptr
+    const uint32_t* fat_docs;       // dirdocs[] entry of every fat slot (doc array) or nullptr
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;

@@ -55,6 +55,44 @@ __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
+// Output staging: values < 65536 of the aligned group of 8 outputs [g8, g8+8) are collected
+// as u16 in two registers while the walk descends and written as two 16-byte stores when
+// the group is complete (one full 32-byte sector); groups cut by the read's ends fall back
+// to scalar stores of the covered elements.
+__device__ __forceinline__ void stage8(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out,
+                                       uint64_t gi, uint32_t xi, uint64_t base, uint32_t m) {
+    const uint32_t slot = (uint32_t)gi & 7;
+    const uint64_t v = (uint64_t)value << ((slot & 3) * 16);
+    if (slot & 4)
+        hi |= v;
+    else
+        lo |= v;
+    if (slot == 0 || xi == 0) {
+        const uint64_t g8 = gi & ~7ull;
+        uint32_t* o = out + g8;
+        const bool full_lo = (g8 >= base) && (g8 + 3 < base + m);
+        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 < base + m);
+        if (full_lo)
+            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo & 0xffff, (uint32_t)(lo >> 16) & 0xffff,
+                                                      (uint32_t)(lo >> 32) & 0xffff, (uint32_t)(lo >> 48));
+        if (full_hi)
+            *reinterpret_cast<uint4*>(o + 4) = make_uint4((uint32_t)hi & 0xffff, (uint32_t)(hi >> 16) & 0xffff,
+                                                          (uint32_t)(hi >> 32) & 0xffff, (uint32_t)(hi >> 48));
+        if (!full_lo || !full_hi) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool covered = t < 4 ? full_lo : full_hi;
+                const uint64_t gt = g8 + t;
+                if (!covered && gt >= gi && gt < base + m) {
+                    const uint64_t wv = t < 4 ? lo : hi;
+                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
+                }
+            }
+        }
+        lo = hi = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
 // ---------------------------------------------------------------------------
@@ -97,7 +135,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // character window: 32 bytes starting at byte offset wbase of seqs
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, wbase = 0;
     // output staging (PML): 8 u16 values of the aligned group of 8 outputs
-    uint64_t ob_lo = 0, ob_hi = 0;
+    uint64_t ob_lo = 0, ob_hi = 0, db_lo = 0, db_hi = 0;
+    uint64_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;  // MS pointers of the aligned group of 4
     // classifier
     uint32_t bin_lo = 0, bin_max = 0, above = 0, below = 0;
     uint64_t sum_max = 0;
@@ -109,10 +148,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     while (ph != P_DONE) {
         // ---- the one gather of this iteration -------------------------------
         const char* p0;
+        uint64_t fidx = 0;  // fat-table slot (P_FAT only)
         if (ph == P_LAND) {
             p0 = rows_b + (uint64_t)k0 * sizeof(Row);
         } else if (ph == P_FAT) {
-            p0 = fat_b + ((uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift)) * sizeof(JumpRow);
+            fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
+            p0 = fat_b + fidx * sizeof(JumpRow);
         } else if (ph == P_DIR) {
             p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
         } else if (ph == P_QS) {
@@ -123,8 +164,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             p0 = off_b + rd * 8;
         } else if (MODE == SPX_MODE_MS && ph == P_SAMP) {
             p0 = reinterpret_cast<const char*>(ix.ss_by_run + k);
-        } else if (MODE == SPX_MODE_MS && ph == P_AUX) {
-            p0 = reinterpret_cast<const char*>(ix.samples + jdir);
         } else {
             p0 = rows_b;
         }
@@ -132,9 +171,20 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         const V16 ga = *reinterpret_cast<const V16*>(p0);
         V16 gb{0, 0, 0, 0};
         if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
+        // side data of the jump row being fetched travels in parallel with it: MS samples
+        // {samples_start[q], samples_last[previous c-run]} and doc ids {start_runs_doc[q],
+        // end_runs_doc[previous c-run]}, from the fat copies (P_FAT) or by directory position
+        SamplePair sp{0, 0};
+        if (MODE == SPX_MODE_MS) {
+            const SamplePair* ps = (ph == P_FAT) ? ix.fat_samples + fidx
+                                                 : ix.samples + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
+            sp = *ps;
+        }
         uint32_t dd = 0;
         if (DOC) {
-            const uint32_t* pd = (ph == P_SAMP) ? ix.rundocs + k : ix.dirdocs + ((ph == P_AUX) ? jdir : 0);
+            const uint32_t* pd = (ph == P_SAMP)  ? ix.rundocs + k
+                                 : (ph == P_FAT) ? ix.fat_docs + fidx
+                                                 : ix.dirdocs + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
             dd = *pd;
         }
         const uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
@@ -216,7 +266,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 k0 = ix.init_k;           // pos = bwt_size() - 1   (:243 / :574)
                 offp = ix.init_off;
                 wbase = ~0ull;            // no characters loaded yet
-                ob_lo = ob_hi = 0;
+                ob_lo = ob_hi = db_lo = db_hi = 0;
                 if (want_class) {
                     const uint32_t w = (uint32_t)b.bin_width;
                     const uint32_t nb = m / w > 0 ? m / w : 1;
@@ -227,10 +277,10 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 ph = P_LAND;
             }
         } else if (ph == P_AUX) {
-            // side data of directory position jdir: {samples_start[Q[j]], samples_last[Q[j-1]]}
-            // and {start_runs_doc[Q[j]], end_runs_doc[Q[j-1]]}
-            if (MODE == SPX_MODE_MS) sample = aux_take ? g1 : g0;  // :601 / :611
-            if (DOC) doc = aux_take ? (dd >> 16) : (dd & 0xffff);   // :317 / :327
+            // only the inconsistent-threshold case of Appendix C1 comes here: side data of the
+            // directory position AFTER run k (samples_last[k] / end_runs_doc[k])
+            if (MODE == SPX_MODE_MS) sample = sp.se;
+            if (DOC) doc = dd >> 16;
             do_emit = true;
         } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1): stays there
             if (MODE == SPX_MODE_MS) sample = g0;  // samples_start[run of pos]
@@ -288,9 +338,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     offp = ps ? soff - 1 : jr_pLFoff(e);
                 }
             }
-            if (AUX) {
-                ph = P_AUX;
+            if (AUX && quirk && below_thr && off > 0) {
+                ph = P_AUX;  // needs the NEXT directory position's side data (jdir was advanced)
             } else {
+                if (MODE == SPX_MODE_MS) sample = aux_take ? sp.se : sp.ss;   // :601 / :611
+                if (DOC) doc = aux_take ? (dd >> 16) : (dd & 0xffff);          // :317 / :327
                 do_emit = true;
             }
         }
@@ -349,50 +401,38 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             const uint32_t xi = x - 1;
             const uint64_t gi = base + xi;
             if (MODE == SPX_MODE_PML) {
-                // lengths[m-i-1] = length (:281), staged 8 at a time (u16) when the read is short
-                if (m < 65536) {
-                    const uint32_t slot = (uint32_t)gi & 7;
-                    const uint64_t v = (uint64_t)length << ((slot & 3) * 16);
-                    if (slot & 4)
-                        ob_hi |= v;
-                    else
-                        ob_lo |= v;
-                    if (slot == 0 || xi == 0) {
-                        // flush the group [g8, g8+8) restricted to this read's range
-                        const uint64_t g8 = gi & ~7ull;
-                        uint32_t* o = b.out_lengths + g8;
-                        const bool full_lo = (g8 >= base) && (g8 + 3 < base + m);
-                        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 < base + m);
-                        if (full_lo) {
-                            uint4 v4 = make_uint4((uint32_t)ob_lo & 0xffff, (uint32_t)(ob_lo >> 16) & 0xffff,
-                                                  (uint32_t)(ob_lo >> 32) & 0xffff, (uint32_t)(ob_lo >> 48));
-                            *reinterpret_cast<uint4*>(o) = v4;
-                        }
-                        if (full_hi) {
-                            uint4 v4 = make_uint4((uint32_t)ob_hi & 0xffff, (uint32_t)(ob_hi >> 16) & 0xffff,
-                                                  (uint32_t)(ob_hi >> 32) & 0xffff, (uint32_t)(ob_hi >> 48));
-                            *reinterpret_cast<uint4*>(o + 4) = v4;
-                        }
-                        if (!full_lo || !full_hi) {
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                const bool covered = t < 4 ? full_lo : full_hi;
-                                const uint64_t gt = g8 + t;
-                                if (!covered && gt >= gi && gt < base + m) {
-                                    const uint64_t wv = t < 4 ? ob_lo : ob_hi;
-                                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
-                                }
-                            }
-                        }
-                        ob_lo = ob_hi = 0;
-                    }
-                } else {
+                // lengths[m-i-1] = length   (:281)
+                if (m < 65536)
+                    stage8(ob_lo, ob_hi, length, b.out_lengths, gi, xi, base, m);
+                else
                     b.out_lengths[gi] = length;
-                }
             } else {
-                b.out_pointers[gi] = sample;  // :618
+                // ms_pointers[m-i-1] = sample   (:618), staged 4 at a time
+                const uint32_t slot = (uint32_t)gi & 3;
+                pb0 = slot == 0 ? sample : pb0;
+                pb1 = slot == 1 ? sample : pb1;
+                pb2 = slot == 2 ? sample : pb2;
+                pb3 = slot == 3 ? sample : pb3;
+                if (slot == 0 || xi == 0) {
+                    const uint64_t g4 = gi & ~3ull;
+                    uint64_t* o = b.out_pointers + g4;
+                    if (g4 >= base && g4 + 3 < base + m) {
+                        *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(pb0, pb1);
+                        *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(pb2, pb3);
+                    } else {
+                        if (g4 + 0 >= gi && g4 + 0 < base + m) o[0] = pb0;
+                        if (g4 + 1 >= gi && g4 + 1 < base + m) o[1] = pb1;
+                        if (g4 + 2 >= gi && g4 + 2 < base + m) o[2] = pb2;
+                        if (g4 + 3 >= gi && g4 + 3 < base + m) o[3] = pb3;
+                    }
+                }
             }
-            if (DOC) b.out_docs[gi] = doc;  // :336 / :677
+            if (DOC) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
+                if (m < 65536)
+                    stage8(db_lo, db_hi, doc, b.out_docs, gi, xi, base, m);
+                else
+                    b.out_docs[gi] = doc;
+            }
             if (want_class) {
                 if (xi < bin_lo) {  // crossed into the previous bin (descending index)
                     if (bin_max >= b.max_value_thr)
@@ -435,20 +475,65 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
 // ---------------------------------------------------------------------------
 // MS length extension: ms_t::matching_statistics second loop
 // (compute_ms_pml.cpp:800-810) with plain text in HBM instead of the SLP.
-// One lane per read; `l` is carried exactly like the reference.
+// One lane per read; `l` is carried exactly like the reference; characters are
+// compared eight at a time (two aligned 64-bit loads + funnel shift per side).
 // ---------------------------------------------------------------------------
+// ascending counterpart of stage8 (the extension walks a read left to right)
+__device__ __forceinline__ void stage8_up(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out,
+                                          uint64_t gi, bool last, uint64_t base) {
+    const uint32_t slot = (uint32_t)gi & 7;
+    const uint64_t v = (uint64_t)value << ((slot & 3) * 16);
+    if (slot & 4)
+        hi |= v;
+    else
+        lo |= v;
+    if (slot == 7 || last) {
+        const uint64_t g8 = gi & ~7ull;
+        uint32_t* o = out + g8;
+        const bool full_lo = (g8 >= base) && (g8 + 3 <= gi);
+        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 <= gi);
+        if (full_lo)
+            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo & 0xffff, (uint32_t)(lo >> 16) & 0xffff,
+                                                      (uint32_t)(lo >> 32) & 0xffff, (uint32_t)(lo >> 48));
+        if (full_hi)
+            *reinterpret_cast<uint4*>(o + 4) = make_uint4((uint32_t)hi & 0xffff, (uint32_t)(hi >> 16) & 0xffff,
+                                                          (uint32_t)(hi >> 32) & 0xffff, (uint32_t)(hi >> 48));
+        if (!full_lo || !full_hi) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool covered = t < 4 ? full_lo : full_hi;
+                const uint64_t gt = g8 + t;
+                if (!covered && gt >= base && gt <= gi) {
+                    const uint64_t wv = t < 4 ? lo : hi;
+                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
+                }
+            }
+        }
+        lo = hi = 0;
+    }
+}
+
+__device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* base, uint64_t idx) {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(base) + (idx >> 3);
+    const uint32_t sh = (uint32_t)(idx & 7) * 8;
+    const uint64_t lo = w[0];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (w[1] << (64 - sh));
+}
+
 __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const BatchArgs b) {
     const uint64_t rd = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
     if (rd >= b.nreads) return;
     const uint64_t base = b.offs[rd];
     const uint64_t m = b.offs[rd + 1] - base;
-    const uint8_t* read = b.seqs + base;
-    const uint64_t* ptrs = b.out_pointers + base;
     uint32_t* out = b.out_lengths + base;
     const uint8_t* text = ix.text;
     const uint64_t n = ix.n_text;
     const bool want_class = b.out_class != nullptr;
     uint64_t l = 0, prev = 0;
+    uint64_t ob_lo = 0, ob_hi = 0;         // staged lengths (u16) of the aligned group of 8
+    uint64_t pc0 = 0, pc1 = 0;             // pointers of the aligned pair holding index i
+    const bool staged = m < 65536;
     // classifier over ascending indices
     const uint64_t w = b.bin_width ? b.bin_width : 1;
     const uint64_t nb = m / w > 0 ? m / w : 1;
@@ -457,13 +542,34 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     uint32_t bin_max = 0, above = 0, below = 0;
     uint64_t sum_max = 0;
     for (uint64_t i = 0; i < m; ++i) {
-        const uint64_t pos = ptrs[i];
-        const bool cont = (i >= 1) && (pos == prev + 1);
-        if (!cont) {
-            // unsigned arithmetic as upstream: pos + l may wrap for wrapped pointers (C3)
-            while ((i + l) < m && (pos + l) < n && read[i + l] == text[pos + l]) ++l;
+        // pointers are fetched two at a time (one aligned 16-byte load per pair)
+        const uint64_t gi = base + i;
+        if ((gi & 1) == 0 || i == 0) {
+            const ulonglong2 pp = *reinterpret_cast<const ulonglong2*>(b.out_pointers + (gi & ~1ull));
+            pc0 = pp.x;
+            pc1 = pp.y;
         }
-        out[i] = (uint32_t)l;
+        const uint64_t pos = (gi & 1) ? pc1 : pc0;
+        const bool cont = (i >= 1) && (pos == prev + 1);  // (i < 1 || pos != pointers[i-1] + 1)
+        if (!cont) {
+            // while (i+l < m && pos+l < n && read[i+l] == text[pos+l]) ++l;   unsigned arithmetic
+            // as upstream: pos + l may wrap for wrapped pointers (Appendix C3)
+            for (;;) {
+                const uint64_t ti = pos + l;
+                if (i + l >= m || ti >= n) break;
+                uint64_t lim = m - (i + l);
+                if (n - ti < lim) lim = n - ti;
+                const uint64_t x = load8_unaligned(b.seqs, base + i + l) ^ load8_unaligned(text, ti);
+                const uint64_t eq = x ? (uint64_t)(__builtin_ctzll(x) >> 3) : 8;  // equal leading bytes
+                const uint64_t adv = eq < lim ? eq : lim;  // never past the end of the read / text
+                l += adv;
+                if (adv < 8) break;  // mismatch, or an end reached inside this word
+            }
+        }
+        if (staged)
+            stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, gi, i + 1 == m, base);
+        else
+            out[i] = (uint32_t)l;
         if (want_class) {
             if (i >= bin_hi) {
                 if (bin_max >= b.max_value_thr)
