@@ -154,7 +154,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
         trun = thr >= n ? r : upper_bound_u64(S, r, thr) - 1;
         toff = thr - S[trun];
     }
-    rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k]);
+    rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
     // predecessor landing = LF(S[k]) - 1 = LF of the last character of the previous run in
     // directory order
     bool psame = false;
@@ -182,7 +182,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
 
 __global__ void k_sentinel_rows(Row* rows, uint64_t r) {
     int t = threadIdx.x;
-    if (t < ROW_PAD) rows[r + t] = pack_row(0, MASK40, (uint32_t)r, 0, true);
+    if (t < ROW_PAD) rows[r + t] = pack_row(0, MASK40, (uint32_t)r, 0, true, ROOM_SAT);
 }
 
 // block count table: cnt[lid][b] = directory offset of the first c-run with index >= b << s

@@ -45,18 +45,24 @@ constexpr int Q_PAD = 16;   // padding entries after (and 1 before) the director
 
 struct alignas(16) Row {
     uint64_t q0;  // len[40] | H[8] << 40 | LFrun[0:16] << 48
-    uint64_t q1;  // LFoff[40] | LFrun[16:32] << 40 | thr_ok << 56
+    uint64_t q1;  // LFoff[40] | LFrun[16:32] << 40 | thr_ok << 56 | room[7] << 57
 };
+constexpr uint32_t ROOM_SAT = 127;
 
 // thr_ok: thresholds[k] <= S[k] (true for every consistent index): lets a byte >= 128
 // that equals the head of its run (signed-char quirk) stay put
 // without looking the threshold up.
-SPX_HD Row pack_row(uint32_t H, uint64_t len, uint32_t LFrun, uint64_t LFoff, bool thr_ok) {
+// room: len[LFrun] - LFoff, saturated at ROOM_SAT -- how far a match step may move inside the
+// destination run.  Knowing it BEFORE the gather lets a step whose offset exceeds it go
+// straight to row LFrun + 1 instead of loading row LFrun only to skip it.
+SPX_HD Row pack_row(uint32_t H, uint64_t len, uint32_t LFrun, uint64_t LFoff, bool thr_ok, uint64_t room) {
     Row r;
+    const uint64_t rm = room < ROOM_SAT ? room : ROOM_SAT;
     r.q0 = (len & MASK40) | ((uint64_t)(H & 0xff) << 40) | ((uint64_t)(LFrun & 0xffff) << 48);
-    r.q1 = (LFoff & MASK40) | ((uint64_t)(LFrun >> 16) << 40) | ((uint64_t)(thr_ok ? 1 : 0) << 56);
+    r.q1 = (LFoff & MASK40) | ((uint64_t)(LFrun >> 16) << 40) | ((uint64_t)(thr_ok ? 1 : 0) << 56) | (rm << 57);
     return r;
 }
+SPX_HD uint32_t row_room(const Row& r) { return (uint32_t)(r.q1 >> 57); }
 SPX_HD uint64_t row_len(const Row& r) { return r.q0 & MASK40; }
 SPX_HD uint32_t row_H(const Row& r) { return (uint32_t)(r.q0 >> 40) & 0xff; }
 SPX_HD uint32_t row_LFrun(const Row& r) {

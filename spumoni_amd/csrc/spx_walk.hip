@@ -55,6 +55,15 @@ __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
+// LF of position (k, off) given row k's move pointer: the run LFrun at offset LFoff + off, or --
+// when the row's `room` says the offset overshoots that run -- the next run directly.
+__device__ __forceinline__ void lf_target(uint32_t LFrun, uint64_t LFoff, uint32_t room, uint64_t off,
+                                          uint32_t& k0, uint64_t& offp) {
+    const bool over = room < ROOM_SAT && off >= room;
+    k0 = LFrun + (over ? 1u : 0u);
+    offp = over ? off - room : LFoff + off;
+}
+
 // Output staging: values < 65536 of the aligned group of 8 outputs [g8, g8+8) are collected
 // as u16 in two registers while the walk descends and written as two 16-byte stores when
 // the group is complete (one full 32-byte sector); groups cut by the read's ends fall back
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint64_t base = 0;
     uint32_t m = 0, x = 0;  // x = characters still to search; next one is index x-1
     // landed position: run k, offset off; fields of row k
-    uint32_t k = 0, H_k = 0, LFrun_k = 0;
+    uint32_t k = 0, H_k = 0, LFrun_k = 0, room_k = 0;
     uint64_t off = 0, LFoff_k = 0;
     bool thr_ok_k = true;
     // landing target
@@ -210,6 +219,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 LFrun_k = row_LFrun(ra);
                 LFoff_k = row_LFoff(ra);
                 thr_ok_k = row_thr_ok(ra);
+                room_k = row_room(ra);
                 do_step = true;
             }
         } else if (ph == P_FAT) {
@@ -285,8 +295,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1): stays there
             if (MODE == SPX_MODE_MS) sample = g0;  // samples_start[run of pos]
             if (DOC) doc = dd & 0xffff;            // start_runs_doc[run of pos]
-            k0 = LFrun_k;
-            offp = LFoff_k + off;
+            lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
             do_emit = true;
         }
 
@@ -371,8 +380,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
                     length++;
                     sample--;  // :582 (wraps, Appendix C3)
-                    k0 = LFrun_k;
-                    offp = LFoff_k + off;
+                    lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
                     do_emit = true;
                 } else if (k < R && H_k == c && thr_ok_k) {
                     // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
@@ -383,8 +391,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     if (AUX) {
                         ph = P_SAMP;  // sample = samples_start[k], doc = start_runs_doc[k]
                     } else {
-                        k0 = LFrun_k;
-                        offp = LFoff_k + off;
+                        lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
                         do_emit = true;
                     }
                 } else {
