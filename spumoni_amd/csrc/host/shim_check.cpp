@@ -1,6 +1,6 @@
 // shim_check.cpp -- exercises the pml_t / ms_t mirror exactly like the reference's callers do
-// (one matching_statistics call per read) and prints the vectors; the GPU tests diff the
-// output with the oracle's.   usage: shim_check <index prefix> <reads: one per line> <P|M> <doc 0|1>
+// (one matching_statistics call per read) and prints the vectors; the GPU tests compare the
+// output with the CPU checker's.   usage: shim_check <index prefix> <reads: one per line> <P|M> <doc 0|1>
 #include <fstream>
 #include <iostream>
 

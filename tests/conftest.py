@@ -18,3 +18,13 @@ def oracle_mod():
 
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope="session")
+def built_all():
+    """Make sure every native artefact the tests run exists (make is a no-op when up to date)."""
+    import subprocess
+
+    for d in ("spumoni_amd/csrc", "spumoni_amd/csrc/host", "oracle"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, d), "-j4"], stdout=subprocess.DEVNULL)
+    return True

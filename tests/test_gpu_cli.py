@@ -84,9 +84,9 @@ def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, f
 
 
 @pytest.fixture(scope="module")
-def built():
+def built(built_all):
     assert torch.cuda.is_available()
-    assert os.path.exists(HOST_BIN) and os.path.exists(ORC_RUN), "run __graft_entry__.build() first"
+    assert os.path.exists(HOST_BIN) and os.path.exists(ORC_RUN)
 
 
 def test_cli_pml_report_doc(built, tmp_path):
