@@ -135,6 +135,12 @@ int spx_query_batch_device(spx_index *ix, int mode, const uint8_t *d_seqs,
  * (synchronises with that query).                                            */
 int spx_last_walk_stats(spx_index *ix, spx_walk_stats *out);
 
+/* Page-locked host memory for spx_query_batch's buffers: with buffers from
+ * spx_host_alloc the copies run at PCIe DMA speed instead of through a pageable
+ * staging copy (any host memory is accepted; this is only faster).  NULL on failure. */
+void *spx_host_alloc(size_t bytes);
+void spx_host_free(void *p);
+
 /* ---- tuning knobs (optional) --------------------------------------------- */
 /* kernel variant: 0 = auto, 1 = lane-per-read state machine,
  * 64 = wavefront-per-read                                        */

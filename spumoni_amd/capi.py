@@ -33,6 +33,8 @@ EXPORTS = [
     "spx_query_batch_device",
     "spx_last_walk_stats",
     "spx_set_option",
+    "spx_host_alloc",
+    "spx_host_free",
 ]
 
 
@@ -94,6 +96,9 @@ def lib() -> C.CDLL:
         L.spx_query_batch_device.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
         L.spx_last_walk_stats.argtypes = [vp, C.POINTER(SpxWalkStats)]
         L.spx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.spx_host_alloc.restype = vp
+        L.spx_host_alloc.argtypes = [C.c_size_t]
+        L.spx_host_free.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -227,6 +232,27 @@ class Index:
         s = SpxWalkStats()
         _check(lib().spx_last_walk_stats(self._h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in SpxWalkStats._fields_}
+
+
+def pinned_array(shape, dtype):
+    """numpy array backed by spx_host_alloc (page-locked) memory; keep the returned owner alive."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib().spx_host_alloc(max(n, 1))
+    if not p:
+        raise SpxError(lib().spx_last_error().decode())
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    free = lib().spx_host_free
+
+    class _Owner:
+        def __del__(self_inner):
+            try:
+                free(p)
+            except Exception:
+                pass
+
+    return arr, _Owner()
 
 
 def pad_seqs(seqs):

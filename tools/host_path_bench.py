@@ -13,3 +13,19 @@ for rep in range(3):
     out = ix.query_host(capi.SPX_MODE_PML, hs, ho, classify=(150, 5))
     dt = time.time() - t0
     print(f"spx_query_batch (pageable host buffers, 0.44 GB in / 1.92 GB out): {dt*1e3:.1f} ms = {1e7/dt/1e6:.1f} M reads/s")
+
+# the same with page-locked buffers from spx_host_alloc
+import ctypes as C
+tot = hs.size; nreads = ho.size - 1
+ps, o1 = capi.pinned_array((tot,), np.uint8); ps[:] = hs
+po, o2 = capi.pinned_array((nreads + 1,), np.uint64); po[:] = ho
+pl, o3 = capi.pinned_array((tot,), np.uint32)
+pc, o4 = capi.pinned_array((nreads,), capi.CLASS_DTYPE)
+vp = lambda a: a.ctypes.data_as(C.c_void_p)
+for rep in range(3):
+    t0 = time.time()
+    rc = capi.lib().spx_query_batch(ix._h, capi.SPX_MODE_PML, vp(ps), vp(po), nreads, vp(pl), None, None, vp(pc), 150, 5)
+    dt = time.time() - t0
+    assert rc == 0
+    print(f"spx_query_batch (page-locked buffers): {dt*1e3:.1f} ms = {1e7/dt/1e6:.1f} M reads/s")
+assert np.array_equal(pl, out["lengths"])
