@@ -185,11 +185,19 @@ void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, si
 
 struct Outputs {
     std::ofstream lengths, pointers, docs, report;
-    TextBuf tl, tp, td;
 };
 
-void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res) {
-    for (size_t q = 0; q < sb.nreads(); ++q) {
+// Formats reads [lo, hi) of a super-batch into text; run by several host threads at once
+// (the text of 10^6 reads x 200 values is ~0.5 GB: at GPU speed, formatting is the job).
+struct TextChunk {
+    TextBuf tl, tp, td;
+    std::string report;
+};
+
+void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res, size_t lo, size_t hi,
+                  TextChunk& out) {
+    std::ostringstream rep;
+    for (size_t q = lo; q < hi; ++q) {
         const uint64_t a = sb.offs[q], b = sb.offs[q + 1];
         if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
             out.td.header(sb.ids[q]);
@@ -208,21 +216,33 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
             const spx_class& c = res.cls[q];
             const size_t nbins = (size_t)c.bins_above + c.bins_below;
             const bool read_found = (c.bins_above / (c.bins_above + c.bins_below + 0.0) > 0.50);
-            out.report.precision(3);
-            out.report << std::setw(30) << std::left << sb.ids[q] << std::setw(15) << std::left
-                       << (read_found ? "FOUND" : "NOT_PRESENT") << std::setw(26) << std::left
-                       << (c.sum_max_bin_values + 0.0) / nbins << std::setw(12) << std::left
-                       << (size_t)c.bins_above << std::setw(12) << std::left << (size_t)c.bins_below << std::endl;
-        }
-        if (out.tl.s.size() > (8u << 20)) {
-            out.tl.flush(out.lengths);
-            if (o.ms) out.tp.flush(out.pointers);
-            if (o.use_doc) out.td.flush(out.docs);
+            rep.precision(3);
+            rep << std::setw(30) << std::left << sb.ids[q] << std::setw(15) << std::left
+                << (read_found ? "FOUND" : "NOT_PRESENT") << std::setw(26) << std::left
+                << (c.sum_max_bin_values + 0.0) / nbins << std::setw(12) << std::left << (size_t)c.bins_above
+                << std::setw(12) << std::left << (size_t)c.bins_below << '\n';
         }
     }
-    out.tl.flush(out.lengths);
-    if (o.ms) out.tp.flush(out.pointers);
-    if (o.use_doc) out.td.flush(out.docs);
+    out.report = rep.str();
+}
+
+void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res) {
+    const size_t nreads = sb.nreads();
+    size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
+    std::vector<TextChunk> chunks(nt);
+    std::vector<std::thread> th;
+    auto lo_of = [&](size_t t) { return nreads * t / nt; };
+    for (size_t t = 1; t < nt; ++t)
+        th.emplace_back([&, t]() { format_range(o, sb, res, lo_of(t), lo_of(t + 1), chunks[t]); });
+    format_range(o, sb, res, lo_of(0), lo_of(1), chunks[0]);
+    for (auto& x : th) x.join();
+    for (TextChunk& c : chunks) {  // written in input order (the reference's -t 1 order)
+        c.tl.flush(out.lengths);
+        if (o.ms) c.tp.flush(out.pointers);
+        if (o.use_doc) c.td.flush(out.docs);
+        if (o.write_report) out.report.write(c.report.data(), (std::streamsize)c.report.size());
+    }
+    if (o.write_report) out.report.flush();
 }
 
 size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {

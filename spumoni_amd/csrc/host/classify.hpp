@@ -26,6 +26,7 @@ struct RunOptions {  // SpumoniRunOptions, include/spumoni_main.hpp:233-250
     std::vector<int> devices{0};
     std::string text_file;
     size_t super_batch_chars = 64u << 20;
+    size_t format_threads = 1;  // host threads that turn results into text (-t, or the core count)
 };
 
 // One spx_index per device, all built from the same raw index files.

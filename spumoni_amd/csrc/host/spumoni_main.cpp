@@ -19,6 +19,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 
 #include "classify.hpp"
 #include "reads.hpp"
@@ -219,6 +220,9 @@ static int run_main(int argc, char** argv) {
         if (o.devices.empty()) o.devices.push_back(0);
     }
     if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
+    // -t: the reference's helper threads walk the index; here the GPU does, and the threads
+    // format the output text instead (default: up to 16 of the available cores)
+    o.format_threads = o.threads > 1 ? o.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     return run_spumoni(o);
 }
 
