@@ -156,3 +156,57 @@ def test_config1_ecoli_scale(gpu, oracle_mod):
     assert np.array_equal(got["class"]["above"], a)
     # sampled reads are FOUND, reversed (null) reads are not: the classifier separates them
     assert 0.3 < f.mean() < 0.7
+
+
+def _adaptive_reads(orc, letters, nreads, length, rng, p_head=0.7):
+    """Reads built by following the oracle's own walk: with probability p_head the next character
+    is the head of the run the walk sits on (for bytes >= 128 that is the Appendix-C1 situation)."""
+    n = orc.n
+    out = np.zeros((nreads, length), dtype=np.uint8)
+    for q in range(nreads):
+        pos = n - 1
+        for i in range(length):
+            if pos < n and rng.random() < p_head and orc.at(pos) > 1:
+                c = orc.at(pos)
+            else:
+                c = int(letters[rng.integers(0, len(letters))])
+            out[q, length - 1 - i] = c
+            nc = orc.rank(n, c)
+            if nc == 0:
+                pass
+            elif pos < n and orc.at(pos) == c and c < 128:
+                pass
+            else:
+                rnk = orc.rank(pos, c)
+                thr = n + 1
+                nxt = pos
+                if rnk < nc:
+                    j = orc.select(rnk, c)
+                    thr = orc.threshold(orc.run_of_position(j))
+                    nxt = j
+                if pos < thr:
+                    nxt = orc.select(rnk - 1, c)
+                pos = nxt
+            pos = orc.LF(pos, c)
+    offs = np.arange(nreads + 1, dtype=np.int64) * length
+    return out.reshape(-1), offs
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_inconsistent_thresholds_general_path(gpu, oracle_mod, seed):
+    """Thresholds anywhere in [1, n] (not between the neighbouring same-letter runs): every step is
+    still defined upstream, and bytes >= 128 that sit on their own run now take the threshold
+    branch for real (Appendix C1 with pos < thr: select(rnk-1) inside the run / previous run)."""
+    rng = np.random.default_rng(seed)
+    letters = list(range(100, 140))
+    raw = synth.statistical_rlbwt(3000, 40, 3.0, seed=seed, letters=letters, with_samples=True, n_docs=6)
+    thr = raw.thr.clone()
+    nz = thr > 0  # first run of a letter keeps threshold 0 (thr_bv semantics)
+    rnd = torch.from_numpy(rng.integers(1, raw.n + 1, size=raw.r))
+    raw.thr = torch.where(nz, rnd, thr)
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    seqs, offs = _adaptive_reads(orc, letters, 300, 40, rng)
+    hi_on_head = int((seqs >= 128).sum())
+    assert hi_on_head > 1000
+    _, st = _compare_all(oracle_mod, raw, None, seqs, offs)
+    assert st["pred_jumps"] > 0
