@@ -23,7 +23,14 @@ IndexSet::~IndexSet() {
 void IndexSet::load(const RunOptions& o) {
     RawIndex raw;
     std::string err;
-    if (!load_raw_index(o.ref_file, o.ms, raw, err)) fatal_error("%s", err.c_str());
+    if (!load_raw_index(o.ref_file, o.ms, raw, err)) {
+        // no raw run files: fall back to the serialised index the reference's `run` loads
+        std::string err2;
+        RawIndex ser;
+        if (!load_serialized_index(o.ref_file + (o.ms ? ".thrbv.ms" : ".thrbv.spumoni"), o.ms, ser, err2))
+            fatal_error("%s\n       and %s", err.c_str(), err2.c_str());
+        raw = std::move(ser);
+    }
     if (o.use_doc && !load_doc_array(o.ref_file + ".doc", raw, err)) fatal_error("%s", err.c_str());
     std::vector<uint8_t> text;
     if (o.ms) {

@@ -31,4 +31,15 @@ bool write_null_db(const std::string& path, double percentile_value, const std::
                    std::string& err);
 bool read_whole_file(const std::string& path, std::vector<uint8_t>& out);
 
+// Reader of the SERIALISED index the reference's `run` loads: <ref>.thrbv.spumoni (PML) /
+// <ref>.thrbv.ms (MS)  (pml_pointers::load, src/compute_ms_pml.cpp:222-229; ms_pointers::load,
+// :551-562).  First-party framing: u64 terminator_position, F (common.hpp:489-495), then
+// ri::rle_string, [samples_last], 256 x thresholds sparse_sd_vector, [samples_start].
+// The third-party streams inside (ri::rle_string / ri::sparse_sd_vector / ri::huff_string over
+// sdsl::sd_vector, select_support_mcl, wt_huff, int_vector) are parsed from the layouts
+// documented in index_files.cpp.  UNVERIFIED against an upstream-built file: neither library
+// nor such a file is available offline; a structural mismatch is reported as an
+// error, never guessed around.  The result is the raw per-run arrays.
+bool load_serialized_index(const std::string& path, bool is_ms, RawIndex& out, std::string& err);
+
 }  // namespace spumoni_host

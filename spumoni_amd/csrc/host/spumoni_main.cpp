@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "classify.hpp"
+#include "index_files.hpp"
 #include "reads.hpp"
 
 #define SPUMONI_VERSION "2.0.9"  // include/spumoni_main.hpp:24 (the version this build mirrors)
@@ -160,11 +161,10 @@ static void validate(const CliOptions& o) {  // include/spumoni_main.hpp:267-329
     const bool have_raw = is_file(base + ".bwt.heads") && is_file(base + ".bwt.len") && is_file(base + ".thr_pos") &&
                           (o.result_type != 0 || (is_file(base + ".ssa") && is_file(base + ".esa")));
     if (!have_raw) {
+        // the reference's own check (include/spumoni_main.hpp:304-313): the serialised index
         const std::string ser = base + (o.result_type == 0 ? ".thrbv.ms" : ".thrbv.spumoni");
-        if (is_file(ser))
-            fatal_error("found %s but not the raw run files it was built from\n"
-                        "       (.bwt.heads/.bwt.len/.thr_pos[/.ssa/.esa]): this build reads those (spumoni build -k).", ser.data());
-        fatal_warning("The index required for this computation is not available, please use spumoni build.");
+        if (!is_file(ser))
+            fatal_warning("The index required for this computation is not available, please use spumoni build.");
     }
     if (o.k > 4) fatal_warning("small window size (k) cannot be larger than 4 characters.");
     if (o.w < o.k) fatal_warning("large window size (w) should be larger than the small window size (k)");
@@ -239,6 +239,33 @@ static int dump_reads_main(int argc, char** argv) {
     return 0;
 }
 
+// debugging aid used by the CPU tests: dump what the serialised-index reader recovers
+static int dump_index_main(int argc, char** argv) {
+    if (argc < 3) return 1;
+    RawIndex raw;
+    std::string err;
+    if (!load_serialized_index(argv[1], argv[2][0] == 'M', raw, err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    std::printf("n %llu r %zu\n", (unsigned long long)raw.n, raw.heads.size());
+    auto dump = [](const char* tag, const std::vector<uint64_t>& v) {
+        std::printf("%s", tag);
+        for (uint64_t x : v) std::printf(" %llu", (unsigned long long)x);
+        std::printf("\n");
+    };
+    std::printf("heads");
+    for (uint8_t h : raw.heads) std::printf(" %u", (unsigned)h);
+    std::printf("\n");
+    dump("lens", raw.lens);
+    dump("thr", raw.thr);
+    if (!raw.ssa.empty()) {
+        dump("ssa", raw.ssa);
+        dump("esa", raw.esa);
+    }
+    return 0;
+}
+
 static int spumoni_usage() {
     std::fprintf(stderr, "SPUMONI has different sub-commands to run which can used as follows:\n");
     std::fprintf(stderr, "Usage: spumoni <command> [options]\n\n");
@@ -250,6 +277,7 @@ static int spumoni_usage() {
 
 int main(int argc, char** argv) {
     if (argc > 2 && std::strcmp(argv[1], "dump-reads") == 0) return dump_reads_main(argc - 1, argv + 1);
+    if (argc > 3 && std::strcmp(argv[1], "dump-index") == 0) return dump_index_main(argc - 1, argv + 1);
     std::fprintf(stderr, "\n\033[1m\033[31mSPUMONI version: %s \033[0m\n\n", SPUMONI_VERSION);
     if (argc > 1) {
         if (std::strcmp(argv[1], "build") == 0)

@@ -159,3 +159,41 @@ def test_cli_two_device_slots_same_output(built, tmp_path):
         _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d"], "-P")
     finally:
         del os.environ["SPUMONI_GPUS"]
+
+
+def test_cli_reads_the_serialised_index(built, tmp_path):
+    """Only <ref>.fa.thrbv.spumoni present (no raw run files): the CLI must load it through the
+    (unverified-layout) serialised-index reader and still produce the oracle's files."""
+    from tests.sdsl_files import write_thrbv
+
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 46, list(b"ACGT"), nreads=150)
+    raw_dir = tmp_path / "rawcopy"
+    raw_dir.mkdir()
+    import glob
+
+    heads = np.fromfile(prefix + ".bwt.heads", dtype=np.uint8)
+    five = lambda p: np.frombuffer(open(p, "rb").read(), dtype=np.uint8).reshape(-1, 5)  # noqa: E731
+    to_u64 = lambda a: (a.astype(np.uint64) << (8 * np.arange(5, dtype=np.uint64))).sum(1)  # noqa: E731
+    lens, thr = to_u64(five(prefix + ".bwt.len")), to_u64(five(prefix + ".thr_pos"))
+    write_thrbv(prefix + ".thrbv.spumoni", np.maximum(heads, 1), lens, thr)
+    # the oracle harness keeps using the raw files: move them aside for the CLI run
+    for f in glob.glob(prefix + ".bwt.*") + [prefix + ".thr_pos", prefix + ".ssa", prefix + ".esa"]:
+        shutil.copy(f, raw_dir / os.path.basename(f))
+    a_dir = tmp_path / "gpu"
+    shutil.rmtree(a_dir, ignore_errors=True)
+    a_dir.mkdir()
+    _write_fasta(a_dir / "reads.fa", seqs, offs, np.random.default_rng(77))
+    for f in glob.glob(prefix + ".bwt.*") + [prefix + ".thr_pos"]:
+        os.remove(f)
+    r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(a_dir / "reads.fa"), "-n", "-P", "-c"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    b_dir = tmp_path / "orc"
+    shutil.rmtree(b_dir, ignore_errors=True)
+    b_dir.mkdir()
+    shutil.copy(a_dir / "reads.fa", b_dir / "reads.fa")
+    for f in os.listdir(raw_dir):
+        shutil.copy(raw_dir / f, os.path.dirname(prefix) + "/" + f)
+    o = subprocess.run([ORC_RUN, prefix, str(b_dir / "reads.fa"), "P", "0", "1", "150", "n"], capture_output=True)
+    assert o.returncode == 0, o.stderr.decode()
+    for e in (".pseudo_lengths", ".report"):
+        assert filecmp.cmp(str(a_dir / "reads.fa") + e, str(b_dir / "reads.fa") + e, shallow=False), e
