@@ -142,8 +142,9 @@ void *spx_host_alloc(size_t bytes);
 void spx_host_free(void *p);
 
 /* ---- tuning knobs (optional) --------------------------------------------- */
-/* kernel variant: 0 = auto, 1 = lane-per-read state machine,
- * 64 = wavefront-per-read                                        */
+/* keys: "waves_per_cu" (occupancy target, default 12), "lanes_per_wave" (reads per
+ * wavefront, 0 = automatic; 1 = the one-wavefront-per-read mapping of SURVEY 7.1,
+ * kept as a measurable experiment -- see DESIGN.md 4.1)                        */
 int spx_set_option(spx_index *ix, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -289,6 +289,10 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->waves_per_cu = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "lanes_per_wave")) {
+        ix->force_lanes_per_wave = (int)value;
+        return SPX_OK;
+    }
     set_error("unknown option '%s'", key);
     return SPX_E_ARG;
 }

@@ -75,6 +75,7 @@ struct spx_index {
     int waves_per_cu = 0; // 0 = default occupancy target
     int occ_blocks[4] = {0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant
     int num_cus = 0;
+    int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
     std::mutex mu;       // device-buffer queries / options
     std::mutex host_mu;  // host-buffer queries (own the scratch below)
     struct Scratch {

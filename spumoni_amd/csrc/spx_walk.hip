@@ -632,7 +632,15 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     const uint64_t need = (args.nreads + WALK_TPB - 1) / WALK_TPB;
     BatchArgs a = args;
     a.lanes_per_wave = 64;
-    if (need < grid) {
+    if (ix->force_lanes_per_wave > 0) {
+        // experiment knob: 1 = the "one wavefront owns one read" mapping
+        const uint64_t lpw = (uint64_t)(ix->force_lanes_per_wave > 64 ? 64 : ix->force_lanes_per_wave);
+        a.lanes_per_wave = (uint32_t)lpw;
+        const uint64_t waves_needed = (args.nreads + lpw - 1) / lpw;
+        const uint64_t waves_resident = grid * (WALK_TPB / 64);
+        const uint64_t waves = waves_needed < waves_resident ? waves_needed : waves_resident;
+        grid = (waves + (WALK_TPB / 64) - 1) / (WALK_TPB / 64);
+    } else if (need < grid) {
         // Fewer reads than lanes (long-read batches): the walk of a read is one dependent
         // chain, so the batch is latency-bound.  Spread it: 64-thread blocks, one or more per
         // SIMD, and only as many active lanes per wavefront as needed -- a wavefront whose few

@@ -4,9 +4,10 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spumoni_amd import capi, synth
 
-def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3):
+def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3, lpw=0):
     ix = capi.Index.from_raw(raw, 0)
     if waves: ix.set_option("waves_per_cu", waves)
+    if lpw: ix.set_option("lanes_per_wave", lpw); tag = f"{tag} lanes/wave={lpw}"
     total = int(seqs.numel()); nreads = offs.numel() - 1
     d_seqs = capi.pad_seqs(seqs)
     d_len = torch.empty(total, dtype=torch.int32, device="cuda") if mode == capi.SPX_MODE_PML else None
@@ -58,3 +59,10 @@ if which in ("big",):
     seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
     torch.cuda.synchronize(); print("gen", time.time() - t0, flush=True)
     run("C3 r=1e9 minimizer sigma=253 m=44", raw, seqs, offs)
+
+if which in ("lpw",):
+    raw = synth.statistical_rlbwt(1 << 26, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 2_000_000, 44, seed=13)
+    for lpw in (1, 4, 16, 64):
+        for w in (12, 32):
+            run("C3-shape r=2^26, 2M reads", raw, seqs, offs, waves=w, lpw=lpw, reps=2)
