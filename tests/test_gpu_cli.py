@@ -197,3 +197,30 @@ def test_cli_reads_the_serialised_index(built, tmp_path):
     assert o.returncode == 0, o.stderr.decode()
     for e in (".pseudo_lengths", ".report"):
         assert filecmp.cmp(str(a_dir / "reads.fa") + e, str(b_dir / "reads.fa") + e, shallow=False), e
+
+
+def test_end_to_end_from_fasta_with_our_builder(built, tmp_path):
+    """FASTA files -> spumoni_amd.build_index (tooling) -> `spumoni run` -> files identical to the
+    oracle harness run on the same index files; positives classify FOUND."""
+    rng = np.random.default_rng(8)
+    g1 = synth.random_genome(30_000, seed=21)
+    g2 = synth.mutate(g1, seed=22)
+    for name, g in (("a.fa", g1), ("b.fa", g2)):
+        with open(tmp_path / name, "w") as f:
+            f.write(f">{name}\n")
+            s = g.tobytes().decode()
+            for i in range(0, len(s), 70):
+                f.write(s[i : i + 70] + "\n")
+    (tmp_path / "list.txt").write_text(f"{tmp_path / 'a.fa'} 1\n{tmp_path / 'b.fa'} 2\n")
+    ref = str(tmp_path / "idx" / "pan")
+    r = subprocess.run(["python", "-m", "spumoni_amd.build_index", "-l", str(tmp_path / "list.txt"), "-o", ref, "--doc"],
+                       capture_output=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()
+    prefix = ref + ".fa"
+    text = np.fromfile(prefix + ".rawtext", dtype=np.uint8)
+    seqs, offs = synth.sample_reads(text, 400, 180, seed=3)
+    for mode, flags in (("-P", ["-c", "-d"]), ("-M", ["-c", "-d"])):
+        _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, flags, mode)
+    rep = open(tmp_path / "gpu" / "reads.fa.report").read().splitlines()[1:]
+    found = sum("FOUND" in ln and "NOT_PRESENT" not in ln for ln in rep)
+    assert 0.3 * len(rep) < found < 0.7 * len(rep)  # sampled reads FOUND, reversed (null) reads not
