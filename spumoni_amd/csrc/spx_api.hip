@@ -115,6 +115,7 @@ void spx_index_free(spx_index* ix) {
         if (sc.p) (void)hipFree(sc.p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
     delete ix;
 }
 
@@ -156,6 +157,7 @@ static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* l
     SPX_HIP(hipMemset(ix->counters, 0, sizeof(WalkCounters)));
     SPX_HIP(hipEventCreate(&ix->ev0));
     SPX_HIP(hipEventCreate(&ix->ev1));
+    SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
     SPX_HIP(hipDeviceSynchronize());
     return SPX_OK;
 }
@@ -363,6 +365,9 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
+    // the counters / events belong to the index: a query enqueued on another stream waits for
+    // the previous one (queries on one index are serialised, as the header promises)
+    if (ix->have_timing && ix->last_stream != st) SPX_HIP(hipStreamWaitEvent(st, ix->ev_done, 0));
     SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), st));
     BatchArgs a;
     a.seqs = d_seqs;
@@ -387,6 +392,7 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
         rc = launch_ms_extend(ix, a, st);
         if (rc != SPX_OK) return rc;
     }
+    SPX_HIP(hipEventRecord(ix->ev_done, st));
     ix->have_timing = true;
     ix->last_stream = st;
     return SPX_OK;

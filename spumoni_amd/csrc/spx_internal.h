@@ -67,7 +67,7 @@ struct spx_index {
     uint64_t n_text = 0;
     spx::DevIndex view{};
     spx::WalkCounters* counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     bool have_timing = false;
     hipStream_t last_stream = nullptr;
     uint64_t device_bytes = 0;

@@ -66,3 +66,8 @@ if which in ("lpw",):
     for lpw in (1, 4, 16, 64):
         for w in (12, 32):
             run("C3-shape r=2^26, 2M reads", raw, seqs, offs, waves=w, lpw=lpw, reps=2)
+if which in ("mix",):
+    raw = synth.statistical_rlbwt(1 << 28, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    for pf in (1.0, 0.5, 0.0):
+        seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13, positive_fraction=pf)
+        run(f"C3 sigma=253 m=44 positive_fraction={pf}", raw, seqs, offs)
