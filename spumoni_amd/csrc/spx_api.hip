@@ -379,6 +379,7 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     a.out_docs = d_out_docs;
     a.out_class = (mode == SPX_MODE_PML) ? d_out_class : nullptr;
     a.bin_width = bin_width;
+    a.bin_magic = bin_width > 1 ? (uint64_t)(~0ull / bin_width) + 1 : 0;
     a.max_value_thr = max_value_thr;
     a.counters = ix->counters;
     SPX_HIP(hipEventRecord(ix->ev0, st));

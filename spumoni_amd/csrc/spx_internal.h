@@ -41,6 +41,7 @@ struct BatchArgs {
     uint32_t* out_docs;
     spx_class* out_class;
     uint64_t bin_width;
+    uint64_t bin_magic;  // floor(2^64 / bin_width) + 1: division by multiplication in the kernel
     uint64_t max_value_thr;
     WalkCounters* counters;
     uint32_t lanes_per_wave;  // active lanes per wavefront (64 unless the batch is small)

@@ -244,12 +244,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                                    (uint32_t)g2, (uint32_t)(g2 >> 32), (uint32_t)g3, (uint32_t)(g3 >> 32)};
             // window holds Q[jdir .. jdir+8): skip the c-runs with index < k (<= k when sitting
             // on a c-run and looking for that very run)
+            // Q is ascending and "still inside the letter's range" is a prefix property too, so
+            // the entries to skip form a prefix of the window: count them
+            const uint32_t room_q = qend - jdir;  // entries of this letter left from jdir on
             uint32_t skip = 0;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bool before = quirk ? (e[t] < k) : (e[t] < k);
-                skip += (jdir + t < qend && before && skip == (uint32_t)t) ? 1u : 0u;
-            }
+            for (int t = 0; t < 8; ++t) skip += ((uint32_t)t < room_q && e[t] < k) ? 1u : 0u;
             jdir += skip;
             if (skip < 8) ph = P_DIR;
         } else if (ph == P_DIR) {
@@ -279,7 +279,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 ob_lo = ob_hi = db_lo = db_hi = 0;
                 if (want_class) {
                     const uint32_t w = (uint32_t)b.bin_width;
-                    const uint32_t nb = m / w > 0 ? m / w : 1;
+                    // m / w without a divide: bin_magic = floor(2^64 / w) + 1 (exact for m < 2^32)
+                    const uint32_t q = w > 1 ? (uint32_t)__umul64hi((uint64_t)m, b.bin_magic) : m;
+                    const uint32_t nb = q > 0 ? q : 1;
                     bin_lo = (nb - 1) * w;
                     bin_max = above = below = 0;
                     sum_max = 0;

@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spumoni_amd import capi, synth
 
-def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3, lpw=0):
+def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3, lpw=0, no_class=False):
     ix = capi.Index.from_raw(raw, 0)
     if waves: ix.set_option("waves_per_cu", waves)
     if lpw: ix.set_option("lanes_per_wave", lpw); tag = f"{tag} lanes/wave={lpw}"
@@ -13,7 +13,7 @@ def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=
     d_len = torch.empty(total, dtype=torch.int32, device="cuda") if mode == capi.SPX_MODE_PML else None
     d_ptr = torch.empty(total, dtype=torch.int64, device="cuda") if mode == capi.SPX_MODE_MS else None
     d_doc = torch.empty(total, dtype=torch.int32, device="cuda") if docs else None
-    d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda") if mode == capi.SPX_MODE_PML else None
+    d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda") if (mode == capi.SPX_MODE_PML and not no_class) else None
     ms = []
     for _ in range(reps + 1):
         ix.query_device(mode, d_seqs, offs, total, d_lengths=d_len, d_pointers=d_ptr, d_docs=d_doc, d_class=d_cls,
@@ -71,3 +71,9 @@ if which in ("mix",):
     for pf in (1.0, 0.5, 0.0):
         seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13, positive_fraction=pf)
         run(f"C3 sigma=253 m=44 positive_fraction={pf}", raw, seqs, offs)
+
+if which in ("noclass",):
+    raw = synth.statistical_rlbwt(1 << 28, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
+    run("C3 with classifier", raw, seqs, offs)
+    run("C3 without classifier", raw, seqs, offs, no_class=True)
