@@ -210,3 +210,34 @@ def test_inconsistent_thresholds_general_path(gpu, oracle_mod, seed):
     assert hi_on_head > 1000
     _, st = _compare_all(oracle_mod, raw, None, seqs, offs)
     assert st["pred_jumps"] > 0
+
+
+def test_degenerate_indexes(gpu, oracle_mod):
+    """One-run and two-run indexes, reads made of the terminator byte / absent letters."""
+    for heads, lens in (([0], [1]), ([65, 0], [3, 1]), ([0, 65], [1, 5])):
+        raw = synth.RawIndex(heads=torch.tensor(heads, dtype=torch.uint8), lens=torch.tensor(lens, dtype=torch.int64),
+                             thr=torch.zeros(len(heads), dtype=torch.int64), n=sum(lens),
+                             ssa=torch.zeros(len(heads), dtype=torch.int64), esa=torch.zeros(len(heads), dtype=torch.int64),
+                             doc_start=torch.zeros(len(heads), dtype=torch.int64),
+                             doc_end=torch.zeros(len(heads), dtype=torch.int64))
+        seqs = np.array([65, 65, 1, 66, 65, 0, 1, 1, 65], dtype=np.uint8)
+        offs = np.array([0, 4, 4, 9])
+        _compare_all(oracle_mod, raw, None, seqs, offs)
+
+
+def test_limits_are_enforced(gpu):
+    base = dict(heads=torch.tensor([0, 65, 67], dtype=torch.uint8), thr=torch.zeros(3, dtype=torch.int64))
+    # BWT longer than the 40-bit position field
+    with pytest.raises(capi.SpxError):
+        capi.Index.from_raw(synth.RawIndex(lens=torch.tensor([1, 1 << 39, 1 << 39], dtype=torch.int64), n=(1 << 40) + 1, **base), 0)
+    # document id that does not fit 16 bits
+    with pytest.raises(capi.SpxError):
+        capi.Index.from_raw(synth.RawIndex(lens=torch.tensor([1, 2, 3], dtype=torch.int64), n=6,
+                                           doc_start=torch.tensor([0, 70000, 1]), doc_end=torch.tensor([0, 1, 1]), **base), 0)
+    # MS query on a PML-only index, docs on an index without a document array
+    ix = capi.Index.from_raw(synth.RawIndex(lens=torch.tensor([1, 2, 3], dtype=torch.int64), n=6, **base), 0)
+    rd, offs = np.array([65, 67], dtype=np.uint8), np.array([0, 2])
+    with pytest.raises(capi.SpxError):
+        ix.query_host(capi.SPX_MODE_MS, rd, offs)
+    with pytest.raises(capi.SpxError):
+        ix.query_host(capi.SPX_MODE_PML, rd, offs, want_docs=True)
