@@ -77,3 +77,16 @@ if which in ("noclass",):
     seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
     run("C3 with classifier", raw, seqs, offs)
     run("C3 without classifier", raw, seqs, offs, no_class=True)
+if which in ("realdna",):
+    # real BWT: 10 haplotypes (1 % SNPs + indels vs a 20 Mbp random base genome) + reverse complements
+    t0 = time.time()
+    base = synth.random_genome(20_000_000, seed=1)
+    genomes = [base] + [synth.mutate(base, seed=s) for s in range(2, 11)]
+    text, doc_lengths = synth.pangenome_text(genomes)
+    print(f"text {text.size/1e6:.0f} Mbp in {time.time()-t0:.1f}s", flush=True)
+    t0 = time.time()
+    raw = synth.index_from_text(torch.from_numpy(text).cuda(), doc_lengths=doc_lengths, with_samples=False)
+    torch.cuda.synchronize(); print(f"index (SA + LCP + thresholds on the GPU) {time.time()-t0:.1f}s", flush=True)
+    nreads, m = 5_000_000, 200
+    seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
+    run("real BWT, 10-hap 20 Mbp pangenome, 5M x 200 bp", raw, torch.from_numpy(seqs).cuda(), torch.from_numpy(offs).cuda())
