@@ -283,10 +283,6 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         return SPX_E_ARG;
     }
     std::lock_guard<std::mutex> g(ix->mu);
-    if (!strcmp(key, "variant")) {
-        ix->variant = (int)value;
-        return SPX_OK;
-    }
     if (!strcmp(key, "waves_per_cu")) {
         ix->waves_per_cu = (int)value;
         return SPX_OK;

@@ -72,7 +72,6 @@ struct spx_index {
     bool have_timing = false;
     hipStream_t last_stream = nullptr;
     uint64_t device_bytes = 0;
-    int variant = 0;      // 0 auto, 1 lane-per-read, 64 wave-per-read
     int waves_per_cu = 0; // 0 = default occupancy target
     int occ_blocks[4] = {0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant
     int num_cus = 0;
