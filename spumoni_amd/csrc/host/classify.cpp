@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -9,6 +11,8 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "index_files.hpp"
@@ -275,44 +279,214 @@ size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
 
 }  // namespace
 
+namespace {
+
+// A super-batch in flight plus what has to happen after it was written.
+struct Slot {
+    SuperBatch sb;
+    Results res;
+    bool last = false;           // no more input after this one
+    int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
+    std::string deferred_msg;
+};
+
+// blocking hand-off of slot indices between the three stages (parse -> GPU -> write)
+class SlotQueue {
+public:
+    void push(int v) {
+        std::lock_guard<std::mutex> g(mu_);
+        q_.push_back(v);
+        cv_.notify_one();
+    }
+    int pop() {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !q_.empty(); });
+        int v = q_.front();
+        q_.erase(q_.begin());
+        return v;
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<int> q_;
+};
+
+// Fills `slot` from the input: segmentation replayed sequentially (reads.cpp), the batches of
+// the super-batch parsed by several threads, reads upper-cased while they are copied into the
+// page-locked buffer.  A malformed / empty read truncates the super-batch there and is reported
+// after everything before it has been written, like the reference running read by read.
+void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_done) {
+    slot.sb.clear();
+    slot.last = false;
+    slot.deferred = 0;
+    std::vector<ReadFile::Range> ranges;
+    size_t bytes = 0;
+    while (!input_done && bytes < o.super_batch_chars) {
+        ReadFile::Range r;
+        if (!input.next_range(1000, r)) {  // reader.loadBatch(input_file, 1000)   (:903)
+            input_done = true;
+            break;
+        }
+        bytes += r.bytes;
+        ranges.push_back(r);
+    }
+    slot.last = input_done;
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (ranges.size() + 63) / 64));
+    std::vector<std::vector<ParsedRead>> parsed(nt);
+    std::vector<ReadFile::ParseError> errs(nt);
+    std::vector<size_t> err_at(nt, 0);
+    auto work = [&](size_t t) {
+        const size_t lo = ranges.size() * t / nt, hi = ranges.size() * (t + 1) / nt;
+        for (size_t i = lo; i < hi && !errs[t].fatal; ++i) input.parse_range(ranges[i], parsed[t], errs[t]);
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    // where does every thread's part go, and where is the first problem (if any)?
+    std::vector<size_t> take(nt, 0), chars(nt, 0);
+    for (size_t t = 0; t < nt && !slot.deferred; ++t) {
+        if (o.use_promotions || o.use_dna_letters) {
+            if (!parsed[t].empty()) {
+                slot.deferred = 1;
+                slot.deferred_msg =
+                    "minimizer digestion of reads (-m / -a) is not available in this build: the\n"
+                    "       reference delegates it to dnbaker/bonsai, whose source is not available offline\n"
+                    "       (DESIGN.md). Digest the reads beforehand and run with -n.";
+            }
+            break;
+        }
+        for (const ParsedRead& rd : parsed[t]) {
+            if (rd.seq.empty()) {  // :926-931
+                slot.deferred = 2;
+                slot.deferred_msg = rd.id;
+                break;
+            }
+            take[t]++;
+            chars[t] += rd.seq.size();
+        }
+        if (!slot.deferred && errs[t].fatal) {
+            slot.deferred = 1;
+            slot.deferred_msg = errs[t].message;
+        }
+    }
+    if (slot.deferred) slot.last = true;
+    std::vector<size_t> r0(nt + 1, 0), c0(nt + 1, 0);
+    for (size_t t = 0; t < nt; ++t) {
+        r0[t + 1] = r0[t] + take[t];
+        c0[t + 1] = c0[t] + chars[t];
+    }
+    const size_t nreads = r0[nt], nchars = c0[nt];
+    slot.sb.ids.resize(nreads);
+    slot.sb.offs.resize(nreads + 1);
+    slot.sb.offs[0] = 0;
+    slot.sb.seqs.resize_uninit(nchars);
+    auto assemble = [&](size_t t) {
+        size_t rdx = r0[t], cpos = c0[t];
+        for (size_t q = 0; q < take[t]; ++q) {
+            ParsedRead& rd = parsed[t][q];
+            uint8_t* dst = slot.sb.seqs.data() + cpos;
+            const char* src = rd.seq.data();
+            const size_t len = rd.seq.size();
+            // make sure all characters are upper-case (:916-917; ::toupper in the "C" locale)
+            for (size_t i = 0; i < len; ++i) {
+                const unsigned char ch = (unsigned char)src[i];
+                dst[i] = (uint8_t)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
+            }
+            cpos += len;
+            slot.sb.offs[rdx + 1] = cpos;
+            slot.sb.ids[rdx] = std::move(rd.id);
+            rdx++;
+        }
+    };
+    th.clear();
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(assemble, t);
+    assemble(0);
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+namespace {
+struct StageTimer {  // SPUMONI_TIMING=1: per-stage wall time on stderr (ours)
+    const char* name;
+    double total = 0;
+    std::chrono::steady_clock::time_point t0;
+    void start() { t0 = std::chrono::steady_clock::now(); }
+    void stop() { total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 size_t classify_reads(IndexSet& set, const RunOptions& o) {
     Outputs out;
     const size_t max_value_thr = open_outputs_and_threshold(out, o);
+    const bool timing = std::getenv("SPUMONI_TIMING") != nullptr;
+    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_gpu{"gpu (incl. copies)", 0, {}},
+        t_write{"format+write", 0, {}};
+    t_load.start();
     ReadFile input(o.pattern_file);
-    SuperBatch sb;
-    Results res;
-    std::vector<ParsedRead> batch;
+    t_load.stop();
+    // three stages, three slots: the host parses super-batch i+1 and formats/writes i-1 while
+    // the GPUs walk super-batch i; results are written in input order
+    constexpr int NSLOTS = 3;
+    std::vector<Slot> slots(NSLOTS);
+    SlotQueue free_q, parsed_q, computed_q;
+    for (int i = 0; i < NSLOTS; ++i) free_q.push(i);
     size_t num_reads = 0;
-    bool more = true;
-    while (more) {
-        // reader.loadBatch(input_file, 1000) (:903), many of them per GPU super-batch
-        more = input.next_batch(1000, batch);
-        if (more) {
-            for (ParsedRead& rd : batch) {
-                // make sure all characters are upper-case (:916-917)
-                for (char& ch : rd.seq) ch = (char)std::toupper((unsigned char)ch);
-                if (o.use_promotions || o.use_dna_letters)
-                    fatal_error("minimizer digestion of reads (-m / -a) is not available in this build: the\n"
-                                "       reference delegates it to dnbaker/bonsai, whose source is not available offline\n"
-                                "       (DESIGN.md). Digest the reads beforehand and run with -n.");
-                if (rd.seq.length() == 0) {  // :926-931
-                    std::cout << "\n\n";
-                    fatal_warning("%s was empty after digestion, commonly due to reads "
-                                  "consisting of mostly non-ACGT characters. Please remove "
-                                  "read or run SPUMONI without minimizer digestion.", rd.id.data());
-                }
-                sb.seqs.append(reinterpret_cast<const uint8_t*>(rd.seq.data()), rd.seq.size());
-                sb.offs.push_back(sb.seqs.size());
-                sb.ids.push_back(std::move(rd.id));
+    std::thread gpu([&] {
+        for (;;) {
+            const int i = parsed_q.pop();
+            if (i < 0) break;
+            t_gpu.start();
+            if (slots[i].sb.nreads() > 0) run_on_devices(set, o, slots[i].sb, max_value_thr, slots[i].res);
+            t_gpu.stop();
+            computed_q.push(i);
+        }
+        computed_q.push(-1);
+    });
+    std::thread writer([&] {
+        for (;;) {
+            const int i = computed_q.pop();
+            if (i < 0) break;
+            Slot& s = slots[i];
+            t_write.start();
+            if (s.sb.nreads() > 0) write_results(out, o, s.sb, s.res);
+            t_write.stop();
+            num_reads += s.sb.nreads();
+            if (s.deferred == 1) {
+                out.lengths.flush();
+                fatal_error("%s", s.deferred_msg.c_str());
             }
+            if (s.deferred == 2) {
+                out.lengths.flush();
+                out.pointers.flush();
+                out.docs.flush();
+                out.report.flush();
+                std::cout << "\n\n";
+                fatal_warning("%s was empty after digestion, commonly due to reads "
+                              "consisting of mostly non-ACGT characters. Please remove "
+                              "read or run SPUMONI without minimizer digestion.", s.deferred_msg.data());
+            }
+            free_q.push(i);
         }
-        if (sb.nreads() > 0 && (!more || sb.seqs.size() >= o.super_batch_chars)) {
-            run_on_devices(set, o, sb, max_value_thr, res);
-            write_results(out, o, sb, res);
-            num_reads += sb.nreads();
-            sb.clear();
-        }
+    });
+    bool input_done = false;
+    for (;;) {
+        const int i = free_q.pop();
+        t_parse.start();
+        fill_slot(input, o, slots[i], input_done);
+        t_parse.stop();
+        const bool last = slots[i].last;
+        parsed_q.push(i);
+        if (last) break;
     }
+    parsed_q.push(-1);
+    gpu.join();
+    writer.join();
+    if (timing)
+        for (StageTimer* t : {&t_load, &t_parse, &t_gpu, &t_write})
+            std::fprintf(stderr, "[timing] %-20s %.3f s\n", t->name, t->total);
     return num_reads;
 }
 

@@ -52,6 +52,15 @@ ReadFile::ReadFile(const std::string& path) {
 
 bool ReadFile::next_batch(size_t num_bases, std::vector<ParsedRead>& out) {
     out.clear();
+    Range r;
+    if (!next_range(num_bases, r)) return false;
+    ParseError err;
+    parse_range(r, out, err);
+    if (err.fatal) fatal_error("%s", err.message.c_str());
+    return true;
+}
+
+bool ReadFile::next_range(size_t num_bases, Range& out) {
     // input type sniffing (batch_loader.cpp:30-38)
     if (format_ == ReadFormat::NotClear) {
         if (data_.empty()) return false;
@@ -98,7 +107,10 @@ bool ReadFile::next_batch(size_t num_bases, std::vector<ParsedRead>& out) {
         }
     }
     if (!valid) return false;
-    parse_batch(first, next_line_, out);
+    out.first = first;
+    out.last = next_line_;
+    out.bytes = 0;
+    for (size_t i = first; i < next_line_; ++i) out.bytes += lines_[i].second - lines_[i].first;
     return true;
 }
 
@@ -106,19 +118,24 @@ static inline void strip_trailing_space(std::string_view& s) {
     while (!s.empty() && std::isspace((unsigned char)s.back())) s.remove_suffix(1);
 }
 
-// grabNextRead (batch_loader.cpp:78-131) over lines [first, last)
-void ReadFile::parse_batch(size_t first, size_t last, std::vector<ParsedRead>& out) const {
-    size_t i = first;
+// grabNextRead (batch_loader.cpp:78-131) over the lines of one batch
+void ReadFile::parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const {
+    const size_t last = r.last;
+    size_t i = r.first;
+    auto fail = [&](const std::string& msg) {
+        err.fatal = true;
+        err.message = msg;
+    };
     while (i < last) {
         std::string_view hdr = line(i++);
         if (hdr.empty()) return;  // an empty header line ends the batch (Appendix C15)
         if (format_ == ReadFormat::Fastq) {
             if (hdr[0] != '@')
-                fatal_error("Incorrect FASTQ entry, it should start with '@' but found %c", hdr[0]);
+                return fail(std::string("Incorrect FASTQ entry, it should start with '@' but found ") + hdr[0]);
         } else if (hdr[0] != '>') {
-            fatal_error("Incorrect FASTA entry, it should start with '>' but found %c", hdr[0]);
+            return fail(std::string("Incorrect FASTA entry, it should start with '>' but found ") + hdr[0]);
         }
-        if (hdr.size() <= 2) fatal_error("header line is missing an id. invalid query cannot be processed.");
+        if (hdr.size() <= 2) return fail("header line is missing an id. invalid query cannot be processed.");
         size_t ws = hdr.find_first_of(" \t\r", 1);
         if (ws == std::string_view::npos) ws = hdr.size();
         ParsedRead rd;

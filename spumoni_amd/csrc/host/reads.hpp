@@ -33,6 +33,22 @@ public:
     // input, or the FASTQ tail quirk C16).  `out` receives the reads of the batch in order.
     bool next_batch(size_t num_bases, std::vector<ParsedRead>& out);
 
+    // The same in two steps, so that many batches can be parsed by several threads:
+    // the segmentation is sequential and cheap, parsing a range is const and thread-safe.
+    struct Range {
+        size_t first = 0, last = 0;  // lines [first, last) of one loadBatch() batch
+        size_t bytes = 0;            // characters in those lines
+    };
+    // A malformed record is fatal in the reference the moment grabNextRead reaches it, i.e.
+    // after every earlier read has been processed and written; parse_range therefore reports
+    // it instead of exiting, together with the reads that precede it.
+    struct ParseError {
+        bool fatal = false;
+        std::string message;  // printed with the FATAL_ERROR shape
+    };
+    bool next_range(size_t num_bases, Range& out);
+    void parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const;
+
     ReadFormat format() const { return format_; }
 
 private:
@@ -46,7 +62,6 @@ private:
     std::string_view line(size_t i) const {
         return std::string_view(data_).substr(lines_[i].first, lines_[i].second - lines_[i].first);
     }
-    void parse_batch(size_t first, size_t last, std::vector<ParsedRead>& out) const;
 };
 
 // error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)

@@ -27,8 +27,9 @@ print(f"wrote reads.fa ({os.path.getsize(d + '/reads.fa')/1e6:.0f} MB) in {time.
 for rep in range(2):
     t0 = time.time()
     r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", f"{d}/reads.fa", "-P", "-c", "-n"],
-                       capture_output=True)
+                       capture_output=True, env=dict(os.environ, SPUMONI_TIMING="1"))
     dt = time.time() - t0
+    print([l for l in r.stderr.decode().splitlines() if "[timing]" in l])
     print(r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "").strip().splitlines()[-4:])
     print(f"spumoni run -P -c -n: {dt:.2f}s wall for {nreads} reads = {nreads/dt/1e6:.2f} M reads/s; "
           f"pseudo_lengths {os.path.getsize(d + '/reads.fa.pseudo_lengths')/1e6:.0f} MB")
