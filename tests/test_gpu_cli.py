@@ -224,3 +224,26 @@ def test_end_to_end_from_fasta_with_our_builder(built, tmp_path):
     rep = open(tmp_path / "gpu" / "reads.fa.report").read().splitlines()[1:]
     found = sum("FOUND" in ln and "NOT_PRESENT" not in ln for ln in rep)
     assert 0.3 * len(rep) < found < 0.7 * len(rep)  # sampled reads FOUND, reversed (null) reads not
+
+
+def test_cli_empty_read_is_fatal_after_earlier_reads_were_written(built, tmp_path):
+    """Appendix C13: a read that is empty is fatal when the reference reaches it -- everything
+    before it has been written by then.  Same files, same exit code, "\\n\\n" on stdout."""
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 47, list(b"ACGT"), nreads=40)
+    for d in ("gpu", "orc"):
+        (tmp_path / d).mkdir(exist_ok=True)
+        with open(tmp_path / d / "reads.fa", "w") as f:
+            for q in range(12):
+                s = seqs[offs[q] : offs[q + 1]].tobytes().decode()
+                if s:
+                    f.write(f">r{q}\n{s}\n")
+            f.write(">bad_one\n>after\nACGTACGT\n")
+    r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(tmp_path / "gpu" / "reads.fa"), "-n", "-P", "-c"],
+                       capture_output=True)
+    o = subprocess.run([ORC_RUN, prefix, str(tmp_path / "orc" / "reads.fa"), "P", "0", "1", "150", "n"], capture_output=True)
+    assert r.returncode == 1 and o.returncode == 1
+    assert b"bad_one was empty after digestion" in r.stderr and b"bad_one was empty after digestion" in o.stderr
+    assert r.stdout.endswith(b"\n\n")
+    for e in (".pseudo_lengths", ".report"):
+        a, b = str(tmp_path / "gpu" / "reads.fa") + e, str(tmp_path / "orc" / "reads.fa") + e
+        assert os.path.getsize(b) > 0 and filecmp.cmp(a, b, shallow=False), e
