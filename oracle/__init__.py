@@ -17,11 +17,9 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "spumoni_oracle.c")
-    hdr = os.path.join(_HERE, "spumoni_oracle.h")
-    stale = (not os.path.exists(so)) or any(
-        os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr)
-    )
+    srcs = [os.path.join(_HERE, f) for f in ("spumoni_oracle.c", "spumoni_oracle_t1.c", "orc_queries.inc",
+                                              "spumoni_oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -58,6 +56,20 @@ def lib() -> C.CDLL:
         L.orc_pml_stats.argtypes = [vp, vp, vp, u64, vp, vp, vp]
         L.orc_max_value_thr.restype = C.c_size_t
         L.orc_max_value_thr.argtypes = [C.c_double, i32, i32, i32]
+        L.orc_t1_build.restype = vp
+        L.orc_t1_build.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
+        L.orc_t1_free.argtypes = [vp]
+        L.orc_t1_run_of_position.restype = u64
+        L.orc_t1_run_of_position.argtypes = [vp, u64]
+        L.orc_t1_at.restype = C.c_uint8
+        L.orc_t1_at.argtypes = [vp, u64]
+        for name in ("orc_t1_rank", "orc_t1_select", "orc_t1_LF"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [vp, u64, C.c_uint8]
+        L.orc_t1_threshold.restype = u64
+        L.orc_t1_threshold.argtypes = [vp, u64]
+        L.orc_t1_pml_batch.argtypes = [vp, vp, vp, u64, vp, vp, i32]
+        L.orc_t1_ms_batch.argtypes = [vp, vp, vp, u64, vp, vp, i32]
         _LIB = L
     return _LIB
 
@@ -157,6 +169,71 @@ class OracleIndex:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         lib().orc_pml_stats(self._h, _p(seqs), _p(offs), offs.size - 1, C.byref(a), C.byref(b), C.byref(c))
         return {"steps": a.value, "jumps": b.value, "pred_jumps": c.value}
+
+
+class OracleT1Index:
+    """Tier T1: Elias-Fano + Huffman wavelet tree + B-run block walk (spumoni_oracle_t1.c)."""
+
+    def __init__(self, heads, lens, thr, ssa=None, esa=None, doc_start=None, doc_end=None):
+        def np_(x):
+            if x is None:
+                return None
+            return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+        heads = np.ascontiguousarray(np_(heads), dtype=np.uint8)
+        lens, thr = _u64(np_(lens)), _u64(np_(thr))
+        ssa, esa = _u64(np_(ssa)), _u64(np_(esa))
+        ds, de = _u64(np_(doc_start)), _u64(np_(doc_end))
+        self.r, self.n = int(heads.size), int(lens.sum())
+        self._h = lib().orc_t1_build(_p(heads), _p(lens), _p(thr), self.r, _p(ssa), _p(esa), _p(ds), _p(de))
+
+    @classmethod
+    def from_raw(cls, raw) -> "OracleT1Index":
+        return cls(raw.heads, raw.lens, raw.thr, raw.ssa, raw.esa, raw.doc_start, raw.doc_end)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:
+            _LIB.orc_t1_free(h)
+
+    def run_of_position(self, p):
+        return lib().orc_t1_run_of_position(self._h, p)
+
+    def at(self, p):
+        return lib().orc_t1_at(self._h, p)
+
+    def rank(self, p, c):
+        return lib().orc_t1_rank(self._h, p, c)
+
+    def select(self, i, c):
+        return lib().orc_t1_select(self._h, i, c)
+
+    def threshold(self, k):
+        return lib().orc_t1_threshold(self._h, k)
+
+    def LF(self, p, c):
+        return lib().orc_t1_LF(self._h, p, c)
+
+    def pml(self, seqs, offs, want_docs=False, nthreads=0):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = _u64(offs)
+        tot = int(offs[-1])
+        out = np.zeros(max(1, tot), dtype=np.uint32)
+        docs = np.zeros_like(out) if want_docs else None
+        lib().orc_t1_pml_batch(self._h, _p(seqs), _p(offs), offs.size - 1, _p(out), _p(docs), nthreads)
+        return (out[:tot], docs[:tot]) if want_docs else out[:tot]
+
+    def ms(self, seqs, offs, want_docs=False, nthreads=0):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = _u64(offs)
+        tot = int(offs[-1])
+        ptrs = np.zeros(max(1, tot), dtype=np.uint64)
+        docs = np.zeros(max(1, tot), dtype=np.uint32) if want_docs else None
+        lib().orc_t1_ms_batch(self._h, _p(seqs), _p(offs), offs.size - 1, _p(ptrs), _p(docs), nthreads)
+        res = {"pointers": ptrs[:tot]}
+        if want_docs:
+            res["docs"] = docs[:tot]
+        return res
 
 
 def classify(lengths, offs, bin_width, max_value_thr):

@@ -286,168 +286,23 @@ uint64_t orc_last_run_sample(const orc_index *ix) {
  * after integer promotion, so bytes >= 128 never match.
  * -------------------------------------------------------------------------- */
 
-/* compute_ms_pml.cpp:238-286 */
-void orc_pml_query(const orc_index *ix, const char *pattern, size_t m, uint64_t *lengths) {
-    uint64_t pos = ix->n - 1; /* :243 */
-    int length = 0;           /* :244  `auto length = 0` is int */
-
-    for (size_t i = 0; i < m; ++i) {
-        char c = pattern[m - i - 1]; /* :247 */
-
-        if (ix->n_c[(uint8_t)c] == 0) {
-            length = 0; /* :249 */
-        } else if (pos < ix->n && (int)orc_at(ix, pos) == (int)c) {
-            length++; /* :250 */
-        } else {
-            uint64_t rnk = orc_rank(ix, pos, (uint8_t)c); /* :253 */
-            size_t thr = ix->n + 1;                       /* :254 */
-            uint64_t next_pos = pos;                      /* :256 */
-
-            if (rnk < ix->n_c[(uint8_t)c]) {              /* :259 */
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);      /* :262 */
-                uint64_t run_of_j = orc_run_of_position(ix, j);    /* :263 */
-                thr = orc_threshold(ix, run_of_j);                 /* :265 */
-                length = 0;
-                next_pos = j;
-            }
-            if (pos < thr) { /* :270 */
-                rnk--;
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c); /* :272 */
-                length = 0;
-                next_pos = j;
-            }
-            pos = next_pos; /* :278 */
-        }
-        lengths[m - i - 1] = (uint64_t)(size_t)length; /* :281 */
-        pos = orc_LF(ix, pos, (uint8_t)c);             /* :284 */
-    }
-}
-
-/* compute_ms_pml.cpp:289-340 */
-void orc_pml_query_doc(const orc_index *ix, const char *pattern, size_t m, uint64_t *lengths,
-                       uint64_t *doc_nums) {
-    uint64_t pos = ix->n - 1;
-    int length = 0;
-    uint64_t curr_doc_id = ix->end_runs_doc[ix->r - 1]; /* :298 */
-
-    for (size_t i = 0; i < m; ++i) {
-        char c = pattern[m - i - 1];
-
-        if (ix->n_c[(uint8_t)c] == 0) {
-            length = 0;
-        } else if (pos < ix->n && (int)orc_at(ix, pos) == (int)c) {
-            length++;
-        } else {
-            uint64_t rnk = orc_rank(ix, pos, (uint8_t)c);
-            size_t thr = ix->n + 1;
-            uint64_t next_pos = pos;
-
-            if (rnk < ix->n_c[(uint8_t)c]) {
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                thr = orc_threshold(ix, run_of_j);
-                curr_doc_id = ix->start_runs_doc[run_of_j]; /* :317 */
-                length = 0;
-                next_pos = j;
-            }
-            if (pos < thr) {
-                rnk--;
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                curr_doc_id = ix->end_runs_doc[run_of_j]; /* :327 */
-                length = 0;
-                next_pos = j;
-            }
-            pos = next_pos;
-        }
-        lengths[m - i - 1] = (uint64_t)(size_t)length;
-        doc_nums[m - i - 1] = curr_doc_id; /* :336 */
-        pos = orc_LF(ix, pos, (uint8_t)c);
-    }
-}
-
-/* compute_ms_pml.cpp:571-623 */
-void orc_ms_query(const orc_index *ix, const char *pattern, size_t m, uint64_t *pointers) {
-    uint64_t pos = ix->n - 1;                    /* :574 */
-    uint64_t sample = orc_last_run_sample(ix);   /* :575 */
-
-    for (size_t i = 0; i < m; ++i) {
-        char c = pattern[m - i - 1];
-
-        if (ix->n_c[(uint8_t)c] == 0) {
-            sample = 0; /* :581 */
-        } else if (pos < ix->n && (int)orc_at(ix, pos) == (int)c) {
-            sample--; /* :582 (unsigned wrap is intended behaviour, Appendix C3) */
-        } else {
-            uint64_t rnk = orc_rank(ix, pos, (uint8_t)c);
-            size_t thr = ix->n + 1;
-            uint64_t next_pos = pos;
-
-            if (rnk < ix->n_c[(uint8_t)c]) {
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                thr = orc_threshold(ix, run_of_j);
-                sample = ix->samples_start[run_of_j]; /* :601 */
-                next_pos = j;
-            }
-            if (pos < thr) {
-                rnk--;
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                sample = ix->samples_last[run_of_j]; /* :611 */
-                next_pos = j;
-            }
-            pos = next_pos;
-        }
-        pointers[m - i - 1] = sample; /* :618 */
-        pos = orc_LF(ix, pos, (uint8_t)c);
-    }
-}
-
-/* compute_ms_pml.cpp:626-682 */
-void orc_ms_query_doc(const orc_index *ix, const char *pattern, size_t m, uint64_t *pointers,
-                      uint64_t *doc_nums) {
-    uint64_t pos = ix->n - 1;
-    uint64_t sample = orc_last_run_sample(ix);
-    uint64_t curr_doc_id = ix->end_runs_doc[ix->r - 1]; /* :634 */
-
-    for (size_t i = 0; i < m; ++i) {
-        char c = pattern[m - i - 1];
-
-        if (ix->n_c[(uint8_t)c] == 0) {
-            sample = 0;
-            uint64_t run_of_j = orc_run_of_position(ix, sample); /* :641 (Appendix C5) */
-            curr_doc_id = ix->start_runs_doc[run_of_j];          /* :642 */
-        } else if (pos < ix->n && (int)orc_at(ix, pos) == (int)c) {
-            sample--;
-        } else {
-            uint64_t rnk = orc_rank(ix, pos, (uint8_t)c);
-            size_t thr = ix->n + 1;
-            uint64_t next_pos = pos;
-
-            if (rnk < ix->n_c[(uint8_t)c]) {
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                thr = orc_threshold(ix, run_of_j);
-                sample = ix->samples_start[run_of_j];
-                curr_doc_id = ix->start_runs_doc[run_of_j]; /* :658 */
-                next_pos = j;
-            }
-            if (pos < thr) {
-                rnk--;
-                uint64_t j = orc_select(ix, rnk, (uint8_t)c);
-                uint64_t run_of_j = orc_run_of_position(ix, j);
-                sample = ix->samples_last[run_of_j];
-                curr_doc_id = ix->end_runs_doc[run_of_j]; /* :669 */
-                next_pos = j;
-            }
-            pos = next_pos;
-        }
-        pointers[m - i - 1] = sample;
-        doc_nums[m - i - 1] = curr_doc_id;
-        pos = orc_LF(ix, pos, (uint8_t)c);
-    }
-}
+#define QFN(name) orc_##name
+#define QIDX orc_index
+#define Q_SIZE(ix) ((ix)->n)
+#define Q_NUMBER_OF_RUNS(ix) ((ix)->r)
+#define Q_NUMBER_OF_LETTER(ix, c) ((ix)->n_c[(c)])
+#define Q_AT(ix, p) orc_at((ix), (p))
+#define Q_RANK(ix, p, c) orc_rank((ix), (p), (c))
+#define Q_SELECT(ix, i, c) orc_select((ix), (i), (c))
+#define Q_RUN_OF_POSITION(ix, p) orc_run_of_position((ix), (p))
+#define Q_THRESHOLD(ix, k) orc_threshold((ix), (k))
+#define Q_LF(ix, p, c) orc_LF((ix), (p), (c))
+#define Q_LAST_RUN_SAMPLE(ix) orc_last_run_sample((ix))
+#define Q_START_DOC(ix, k) ((ix)->start_runs_doc[(k)])
+#define Q_END_DOC(ix, k) ((ix)->end_runs_doc[(k)])
+#define Q_SAMPLE_START(ix, k) ((ix)->samples_start[(k)])
+#define Q_SAMPLE_LAST(ix, k) ((ix)->samples_last[(k)])
+#include "orc_queries.inc"
 
 /* ms_t::matching_statistics, second loop (compute_ms_pml.cpp:800-810) */
 void orc_ms_lengths(const char *read, size_t m, const uint64_t *pointers, const uint8_t *text,

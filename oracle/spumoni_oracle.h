@@ -104,6 +104,24 @@ void orc_classify_batch(const uint32_t *lengths, const uint64_t *offs, uint64_t 
 void orc_pml_stats(const orc_index *ix, const uint8_t *seqs, const uint64_t *offs,
                    uint64_t nreads, uint64_t *steps, uint64_t *jumps, uint64_t *pred_jumps);
 
+/* ---- tier T1: the same queries over Elias-Fano + Huffman wavelet tree + B-run block walk
+ * (spumoni_oracle_t1.c); must agree with the flat tier above bit for bit ----------------- */
+typedef struct orc_t1_index orc_t1_index;
+orc_t1_index *orc_t1_build(const uint8_t *heads, const uint64_t *lens, const uint64_t *thr, uint64_t r,
+                           const uint64_t *samples_start, const uint64_t *samples_last,
+                           const uint64_t *start_runs_doc, const uint64_t *end_runs_doc);
+void orc_t1_free(orc_t1_index *ix);
+uint64_t orc_t1_run_of_position(const orc_t1_index *ix, uint64_t p);
+uint8_t orc_t1_at(const orc_t1_index *ix, uint64_t p);
+uint64_t orc_t1_rank(const orc_t1_index *ix, uint64_t p, uint8_t c);
+uint64_t orc_t1_select(const orc_t1_index *ix, uint64_t i, uint8_t c);
+uint64_t orc_t1_threshold(const orc_t1_index *ix, uint64_t k);
+uint64_t orc_t1_LF(const orc_t1_index *ix, uint64_t p, uint8_t c);
+void orc_t1_pml_batch(const orc_t1_index *ix, const uint8_t *seqs, const uint64_t *offs, uint64_t nreads,
+                      uint32_t *out_lengths, uint32_t *out_docs, int nthreads);
+void orc_t1_ms_batch(const orc_t1_index *ix, const uint8_t *seqs, const uint64_t *offs, uint64_t nreads,
+                     uint64_t *out_pointers, uint32_t *out_docs, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,3 +20,12 @@ try:
     print("cpu.max", open("/sys/fs/cgroup/cpu.max").read())
 except Exception as e:
     print(e)
+
+# tier T1 (Elias-Fano + wavelet tree + block walk: the reference's own structures)
+t0 = time.time(); t1 = oracle.OracleT1Index.from_raw(rawc); print("T1 oracle build", time.time() - t0, flush=True)
+for T in (1, 16, 32):
+    nr = min(400_000, 1000 * T)
+    t0 = time.time(); got = t1.pml(hs[: nr * 44], ho[: nr + 1], nthreads=T); dt = time.time() - t0
+    print(f"T1 threads {T:4d}: {nr} reads in {dt:.2f}s = {nr/dt:.0f} reads/s ({nr/dt/T:.0f}/thread)", flush=True)
+assert np.array_equal(got, orc.pml(hs[: nr * 44], ho[: nr + 1], nthreads=32))
+print("T1 == T2 on the sample")
