@@ -119,9 +119,9 @@ __global__ void k_letters(const uint8_t* Hs, const uint64_t* LFs, const uint64_t
 __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint64_t* LFs,
                              const uint64_t* S, const uint64_t* lens, const uint32_t* nzpos,
                              const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
-                             const uint64_t* de, const LetterInfo* letters, uint64_t r, uint64_t n,
-                             Row* rows, JumpRow* dirrows, uint32_t* dirdocs, uint32_t* rundocs,
-                             unsigned long long* err) {
+                             const uint64_t* de, const LetterInfo* letters, const uint8_t* Hrun,
+                             uint64_t r, uint64_t n, Row* rows, JumpRow* dirrows, uint32_t* dirdocs,
+                             uint32_t* rundocs, unsigned long long* err) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
     uint32_t k = Qall[i];
@@ -157,13 +157,9 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
     rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
     // predecessor landing = LF(S[k]) - 1 = LF of the last character of the previous run in
     // directory order
-    bool psame = false;
-    uint64_t poff = 0;
-    if (i > 0) {
-        psame = soff > 0;
-        poff = psame ? soff - 1 : S[dst] - S[dst - 1] - 1;  // lf > 0 here, so dst >= 1 when !psame
-    }
-    dirrows[i] = pack_jumprow(k, (uint32_t)trun, toff, (uint32_t)dst, soff, psame, poff, (uint32_t)i);
+    const bool psame = soff > 0;  // for i == 0 (lf == 0) there is no predecessor: never taken
+    const uint32_t hs = Hrun[dst], hp = dst > 0 ? Hrun[dst - 1] : 0;
+    dirrows[i] = pack_jumprow(k, (uint32_t)trun, toff, (uint32_t)dst, soff, psame, hs, hp, (uint32_t)i);
     if (dirdocs) {
         uint64_t d0 = ds[k], d1 = de[k], dp = i > 0 ? de[Qall[i - 1]] : 0;
         if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
@@ -175,7 +171,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
         }
     }
     if (i + 1 == r) {  // sentinel jump row r: LF image n, predecessor = position n-1
-        JumpRow sd = pack_jumprow((uint32_t)r, 0, 0, (uint32_t)r, 0, false, S[r] - S[r - 1] - 1, (uint32_t)r);
+        JumpRow sd = pack_jumprow((uint32_t)r, 0, 0, (uint32_t)r, 0, false, 0, Hrun[r - 1], (uint32_t)r);
         for (int t = 0; t < 4; ++t) dirrows[r + t] = sd;
     }
 }
@@ -289,8 +285,6 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     SPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(iota.p);
     iota.p = nullptr;
-    (void)hipFree(H.p);
-    H.p = nullptr;
 
     // LF image of every run start = exclusive scan of lengths in (letter, run) order
     SPX_HIP(ls.alloc(r * 8));
@@ -347,9 +341,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     }
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
-                                              T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters, r,
-                                              n, ix->rows, ix->dirrows, ix->dirdocs, ix->rundocs,
-                                              err.as<unsigned long long>());
+                                              T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters,
+                                              H.as<uint8_t>(), r, n, ix->rows, ix->dirrows, ix->dirdocs,
+                                              ix->rundocs, err.as<unsigned long long>());
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r);
     SPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(T.p);

@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t length = 0, doc = 0;
     uint64_t sample = 0;
     // jump bookkeeping
-    uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0;
-    bool quirk = false;
+    uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0, Hland = 0;
+    bool quirk = false, peek = false;
     // character window: 32 bytes starting at byte offset wbase of seqs
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, wbase = 0;
     // output staging (PML): 8 u16 values of the aligned group of 8 outputs
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             ra.q0 = g0;
             ra.q1 = g1;
             const uint64_t len = row_len(ra);
+            if (offp == OFF_END) offp = len - 1;  // predecessor landing: last position of this run
             if (offp >= len) {  // LF image lies in a later run: skip this row
                 offp -= len;
                 k0++;
@@ -316,17 +317,22 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             const uint64_t soff = jr_sLFoff(e);
             length = 0;
             aux_take = 0;
+            peek = false;
             if (!quirk) {
                 if (!below_thr) {  // next_pos = first position of the next c-run; LF of it
                     k0 = srun;
                     offp = soff;
+                    Hland = jr_Hs(e);
+                    peek = true;
                 } else {  // select(rnk-1, c): last position of the previous c-run; LF of it
                     n_pred++;
                     if (jdir <= qbeg) n_err++;  // rnk-- below zero: undefined upstream
                     aux_take = 1;
                     const bool ps = jr_psame(e);
                     k0 = ps ? srun : srun - 1;
-                    offp = ps ? soff - 1 : jr_pLFoff(e);
+                    offp = ps ? soff - 1 : OFF_END;
+                    Hland = ps ? jr_Hs(e) : jr_Hp(e);
+                    peek = ps;  // the exact offset is only known when it stays in run sLFrun
                 }
             } else {
                 // the walk sits on run k whose head equals c >= 128 (Appendix C1) and
@@ -346,7 +352,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     aux_take = 1;
                     const bool ps = jr_psame(e);
                     k0 = ps ? srun : srun - 1;
-                    offp = ps ? soff - 1 : jr_pLFoff(e);
+                    offp = ps ? soff - 1 : OFF_END;
                 }
             }
             if (AUX && quirk && below_thr && off > 0) {
@@ -469,7 +475,32 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 ph = rd < b.nreads ? P_READ : P_DONE;
             } else {
                 ph = P_LAND;
+                if (peek) {
+                    // The jump row told us the head of the run we land in.  If the next character
+                    // is present in the index and differs from it, the next step is a jump again
+                    // -- from (k0, offp), which is all a jump needs -- and the landing row is
+                    // never fetched.  (Match / byte >= 128 / absent letter: load the row as usual.)
+                    const uint64_t g = base + x - 1;
+                    if (g >= wbase && g - wbase < 32) {
+                        const uint32_t wi = (uint32_t)(g - wbase);
+                        const uint64_t wsel = (wi & 16) ? ((wi & 8) ? w3 : w2) : ((wi & 8) ? w1 : w0);
+                        const uint32_t cn = (uint32_t)(wsel >> ((wi & 7) * 8)) & 0xffu;
+                        const LetterInfo li = s_let[cn];
+                        if (li.lid != NO_LETTER && cn != Hland && k0 < R) {
+                            k = k0;
+                            off = offp;
+                            H_k = Hland;
+                            c = cn;
+                            quirk = false;
+                            qbeg = li.qbeg;
+                            qend = li.qend;
+                            n_jumps++;
+                            ph = P_FAT;
+                        }
+                    }
+                }
             }
+            peek = false;
         }
     }
 
