@@ -8,6 +8,7 @@
 // 10^9-run index is laid out in seconds without touching the host.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <vector>
 
 #include "spx_internal.h"
@@ -353,11 +354,36 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     (void)hipFree(LFs.p);
     LFs.p = nullptr;
 
-    // directory block size: the smallest power of two >= nletters / 3 runs, i.e. a fat table of
-    // at most ~96 B per run (2 runs per block for DNA, 128 for the 253-letter minimizer
-    // alphabet): small enough that the block's fat entry usually IS the successor run
+    // Directory block size = how much HBM is traded for speed.  A fat slot answers a jump
+    // outright when no c-run lies between its block's start and the walk's run, so smaller
+    // blocks mean fewer Q / dirrow gathers (measured on C3, same box: 787 / 804 / 867 / 912 M
+    // reads/s at 128 / 64 / 32 / 16 runs per block, for 29 / 45 / 77 / 140 GiB of index).  The
+    // densest table is taken that keeps the whole flat index within the budget: 60 % of the
+    // memory free on the device right now (SPX_INDEX_BUDGET_GB overrides), never coarser than
+    // nletters / 3 runs per block (~96 B per run).
+    size_t mem_free = 0, mem_total = 0;
+    SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
+    double budget = 0.6 * (double)mem_free;
+    if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
+    const bool has_ms = d_ssa && d_esa;
+    const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
+    const double per_slot = 32 + (has_ms ? 16 : 0) + (docs ? 4 : 0) + 4 /* cnt scratch */;
     uint32_t bshift = 0;
     while ((3u << bshift) < nletters && bshift < 16) bshift++;
+    if (const char* e = getenv("SPX_FAT_BSHIFT")) {  // test / experiment knob: force 2^bshift runs per block
+        bshift = (uint32_t)atoi(e) & 31;
+        if (bshift > 20) bshift = 20;
+    } else if (const char* e = getenv("SPX_FAT_DIV")) {  // experiment knob: force nletters / div runs per block
+        const uint32_t div = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 3;
+        bshift = 0;
+        while ((div << bshift) < nletters && bshift < 16) bshift++;
+    } else {
+        while (bshift > 0) {
+            const double slots = (double)nletters * ((double)(r >> (bshift - 1)) + 2);
+            if ((double)r * per_run + slots * per_slot > budget) break;
+            bshift--;
+        }
+    }
     const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
     const uint64_t nfat = (uint64_t)nletters * nblk;
     DevBuf cnt;

@@ -241,3 +241,18 @@ def test_limits_are_enforced(gpu):
         ix.query_host(capi.SPX_MODE_MS, rd, offs)
     with pytest.raises(capi.SpxError):
         ix.query_host(capi.SPX_MODE_PML, rd, offs, want_docs=True)
+
+
+@pytest.mark.parametrize("bshift", [0, 2, 5, 9])
+def test_every_directory_block_size(gpu, oracle_mod, bshift, monkeypatch):
+    """The fat-table block size is chosen from the free memory; force it from 1 to 512 runs per
+    block so that the direct answer, the one-window and the multi-window directory scans all run."""
+    monkeypatch.setenv("SPX_FAT_BSHIFT", str(bshift))
+    for seed, letters in ((61, DNA), (62, [3, 4, 5, 90, 127, 128, 129, 200, 255])):
+        raw, text = cases.real_case(seed, 6000, letters)
+        rng = np.random.default_rng(seed)
+        seqs, offs = cases.reads_mixed(rng, text, letters, 250, 100, [ord("N")])
+        _, st = _compare_all(oracle_mod, raw, text, seqs, offs)
+    raw = synth.statistical_rlbwt(30000, 16, 2.0, seed=7, device="cuda", with_samples=True, n_docs=5)
+    seqs, offs = synth.simulate_reads(raw, 3000, 50, seed=8, positive_fraction=0.3)
+    _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy())

@@ -90,3 +90,13 @@ if which in ("realdna",):
     nreads, m = 5_000_000, 200
     seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
     run("real BWT, 10-hap 20 Mbp pangenome, 5M x 200 bp", raw, torch.from_numpy(seqs).cuda(), torch.from_numpy(offs).cuda())
+if which in ("fatdiv",):
+    import subprocess
+    raw = synth.statistical_rlbwt(1 << 28, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs5, offs5 = synth.simulate_reads(raw, 10_000_000, 44, seed=13, positive_fraction=0.5)
+    seqs0, offs0 = synth.simulate_reads(raw, 10_000_000, 44, seed=13, positive_fraction=0.0)
+    for rep in range(2):
+        for d in (3, 6, 12, 24):
+            os.environ["SPX_FAT_DIV"] = str(d)
+            run(f"fat div={d} mix 0.5", raw, seqs5, offs5, reps=3)
+            run(f"fat div={d} random", raw, seqs0, offs0, reps=3)
