@@ -141,10 +141,50 @@ int spx_last_walk_stats(spx_index *ix, spx_walk_stats *out);
 void *spx_host_alloc(size_t bytes);
 void spx_host_free(void *p);
 
+/* ---- minimizer digestion (run -m / -a) -------------------------------------
+ * Replaces perform_minimizer_digestion / perform_dna_minimizer_digestion
+ * (src/spumoni.cpp:294-319, 321-342), which the harness applies to every read
+ * before matching_statistics (src/compute_ms_pml.cpp:919-923).  Reads must be
+ * upper-cased already (:916-917).  k in [1,4], w >= k (spumoni_main.hpp:316-317).
+ * The minimizer streams restate dnbaker/bonsai @5273b81a92 (source absent
+ * offline, parity unpinned -- DESIGN.md 4.4); the four 8-bit character hashes
+ * the -m variant depends on can be pinned with
+ * spx_set_option(ix, "minimizer_charhash", A | C<<8 | G<<16 | T<<24).          */
+#define SPX_DIGEST_PROMOTED 1 /* -m: promoted-alphabet minimizers, one byte each   */
+#define SPX_DIGEST_DNA 2      /* -a: minimizer k-mers spelled in DNA letters       */
+/* bytes d_out_seqs must hold for any input of total_chars characters (worst
+ * case + the read-ahead padding spx_query_batch_device wants of its d_seqs)    */
+uint64_t spx_digest_capacity(int kind, uint32_t k, uint64_t total_chars);
+/* Device form: digested reads, concatenated, into d_out_seqs (16-byte aligned if
+ * it is to be queried), their nreads+1 offsets into d_out_offsets; enqueued on
+ * `stream`, returns without synchronising.  d_out_seqs / d_out_offsets can be
+ * handed to spx_query_batch_device as they are (total = d_out_offsets[nreads]). */
+int spx_digest_batch_device(spx_index *ix, int kind, uint32_t k, uint32_t w, const uint8_t *d_seqs,
+                            const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
+                            uint8_t *d_out_seqs, uint64_t out_capacity, uint64_t *d_out_offsets,
+                            void *stream);
+/* Host form.  out_seqs may be NULL with out_capacity 0 to learn the sizes only
+ * (out_offsets is filled, SPX_E_ARG is returned when anything was digested).   */
+int spx_digest_batch(spx_index *ix, int kind, uint32_t k, uint32_t w, const uint8_t *seqs,
+                     const uint64_t *offsets, uint64_t nreads, uint8_t *out_seqs,
+                     uint64_t out_capacity, uint64_t *out_offsets);
+/* Host form of digest + query in one call: what the harness loop body does for
+ * one read (compute_ms_pml.cpp:916-938), for a batch.  The digested reads stay
+ * on the device; out_offsets (nreads+1) receives their offsets, and every
+ * output is laid out at THOSE offsets; out_capacity = entries each output
+ * buffer holds (>= out_offsets[nreads], e.g. spx_digest_capacity()).  A read
+ * that digests to nothing (offsets equal) is the caller's fatal case (:926-931). */
+int spx_digest_query_batch(spx_index *ix, int mode, int kind, uint32_t k, uint32_t w,
+                           const uint8_t *seqs, const uint64_t *offsets, uint64_t nreads,
+                           uint64_t *out_offsets, uint64_t out_capacity, uint32_t *out_lengths,
+                           uint64_t *out_pointers, uint32_t *out_docs, spx_class *out_class,
+                           uint64_t bin_width, uint64_t max_value_thr);
+
 /* ---- tuning knobs (optional) --------------------------------------------- */
 /* keys: "waves_per_cu" (occupancy target, default 12), "lanes_per_wave" (reads per
  * wavefront, 0 = automatic; 1 = the one-wavefront-per-read mapping of SURVEY 7.1,
  * kept as a measurable experiment -- see DESIGN.md 4.1)                        */
+/* "minimizer_charhash": see the digestion section above                        */
 int spx_set_option(spx_index *ix, const char *key, int64_t value);
 
 #ifdef __cplusplus

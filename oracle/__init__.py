@@ -17,7 +17,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("spumoni_oracle.c", "spumoni_oracle_t1.c", "orc_queries.inc",
+    srcs = [os.path.join(_HERE, f) for f in ("spumoni_oracle.c", "spumoni_oracle_t1.c", "orc_digest.c", "orc_queries.inc",
                                               "spumoni_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
     if force or stale:
@@ -70,6 +70,10 @@ def lib() -> C.CDLL:
         L.orc_t1_threshold.argtypes = [vp, u64]
         L.orc_t1_pml_batch.argtypes = [vp, vp, vp, u64, vp, vp, i32]
         L.orc_t1_ms_batch.argtypes = [vp, vp, vp, u64, vp, vp, i32]
+        L.orc_digest_default_charhash.argtypes = [vp]
+        L.orc_digest.restype = C.c_size_t
+        L.orc_digest.argtypes = [i32, C.c_uint, C.c_uint, vp, vp, C.c_size_t, vp, C.c_size_t]
+        L.orc_digest_batch.argtypes = [i32, C.c_uint, C.c_uint, vp, vp, vp, u64, vp, u64, vp]
         _LIB = L
     return _LIB
 
@@ -250,3 +254,34 @@ def classify(lengths, offs, bin_width, max_value_thr):
 
 def max_value_thr(percentile_value, is_pml, use_promotions, use_dna_letters):
     return int(lib().orc_max_value_thr(float(percentile_value), int(is_pml), int(use_promotions), int(use_dna_letters)))
+
+
+DIGEST_PROMOTED, DIGEST_DNA = 1, 2
+
+
+def digest_default_charhash():
+    out = np.zeros(4, dtype=np.uint8)
+    lib().orc_digest_default_charhash(_p(out))
+    return out
+
+
+def digest(kind, k, w, seq, charhash=None):
+    """One read through orc_digest (src/spumoni.cpp:294-342 restated); seq: bytes / uint8 array."""
+    s = np.frombuffer(bytes(seq), dtype=np.uint8) if not isinstance(seq, np.ndarray) else np.ascontiguousarray(seq, dtype=np.uint8)
+    ch = None if charhash is None else np.ascontiguousarray(charhash, dtype=np.uint8)
+    cap = max(1, int(k) * len(s))
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_digest(kind, k, w, _p(ch), _p(s), len(s), _p(out), cap)
+    return out[:n].copy()
+
+
+def digest_batch(kind, k, w, seqs, offs, charhash=None):
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    ch = None if charhash is None else np.ascontiguousarray(charhash, dtype=np.uint8)
+    nreads = len(offs) - 1
+    cap = max(1, int(k) * len(seqs))
+    out = np.zeros(cap, dtype=np.uint8)
+    out_offs = np.zeros(nreads + 1, dtype=np.uint64)
+    lib().orc_digest_batch(kind, k, w, _p(ch), _p(seqs), _p(offs), nreads, _p(out), cap, _p(out_offs))
+    return out[: int(out_offs[-1])].copy(), out_offs

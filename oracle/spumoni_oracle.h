@@ -122,6 +122,16 @@ void orc_t1_pml_batch(const orc_t1_index *ix, const uint8_t *seqs, const uint64_
 void orc_t1_ms_batch(const orc_t1_index *ix, const uint8_t *seqs, const uint64_t *offs, uint64_t nreads,
                      uint64_t *out_pointers, uint32_t *out_docs, int nthreads);
 
+/* ---- minimizer digestion pre-step of `run -m` / `run -a` (orc_digest.c; src/spumoni.cpp:294-342
+ * over a restatement of bonsai's minimizer streams, parity unpinned) ----------------------- */
+#define ORC_DIGEST_PROMOTED 1 /* -m */
+#define ORC_DIGEST_DNA 2      /* -a */
+void orc_digest_default_charhash(uint8_t out[4]);
+size_t orc_digest(int kind, unsigned k, unsigned w, const uint8_t *charhash, const uint8_t *seq, size_t len,
+                  uint8_t *out, size_t cap);
+void orc_digest_batch(int kind, unsigned k, unsigned w, const uint8_t *charhash, const uint8_t *seqs,
+                      const uint64_t *offs, uint64_t nreads, uint8_t *out, uint64_t cap, uint64_t *out_offs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,13 @@ EXPORTS = [
     "spx_set_option",
     "spx_host_alloc",
     "spx_host_free",
+    "spx_digest_capacity",
+    "spx_digest_batch",
+    "spx_digest_batch_device",
+    "spx_digest_query_batch",
 ]
+
+SPX_DIGEST_PROMOTED, SPX_DIGEST_DNA = 1, 2
 
 
 class SpxClass(C.Structure):
@@ -99,6 +105,12 @@ def lib() -> C.CDLL:
         L.spx_host_alloc.restype = vp
         L.spx_host_alloc.argtypes = [C.c_size_t]
         L.spx_host_free.argtypes = [vp]
+        u32 = C.c_uint32
+        L.spx_digest_capacity.restype = u64
+        L.spx_digest_capacity.argtypes = [i32, u32, u64]
+        L.spx_digest_batch.argtypes = [vp, i32, u32, u32, vp, vp, u64, vp, u64, vp]
+        L.spx_digest_batch_device.argtypes = [vp, i32, u32, u32, vp, vp, u64, u64, vp, u64, vp, vp]
+        L.spx_digest_query_batch.argtypes = [vp, i32, i32, u32, u32, vp, vp, u64, vp, u64, vp, vp, vp, vp, u64, u64]
         _LIB = L
     return _LIB
 
@@ -227,6 +239,62 @@ class Index:
             self._h, mode, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars, _t_ptr(d_lengths),
             _t_ptr(d_pointers), _t_ptr(d_docs), _t_ptr(d_class), bin_width, max_value_thr,
             C.c_void_p(st.cuda_stream)))
+
+    # -- minimizer digestion (run -m / -a) ------------------------------------
+    def digest_host(self, kind, k, w, seqs, offs):
+        """(digested seqs, offsets) of a batch of upper-cased reads; host buffers."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        nreads = offs.size - 1
+        tot = int(offs[-1]) if nreads > 0 else 0
+        cap = int(lib().spx_digest_capacity(kind, k, tot))
+        out = np.zeros(cap, dtype=np.uint8)
+        out_offs = np.zeros(nreads + 1, dtype=np.uint64)
+        _check(lib().spx_digest_batch(self._h, kind, k, w, _np_ptr(seqs), _np_ptr(offs), nreads, _np_ptr(out), cap,
+                                      _np_ptr(out_offs)))
+        return out[: int(out_offs[-1])], out_offs
+
+    def digest_device(self, kind, k, w, d_seqs, d_offs, total_chars, stream=None):
+        """Digest on the device; returns (d_out_seqs, d_out_offs) torch tensors that can go
+        straight into query_device (total = d_out_offs[-1])."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        nreads = d_offs.numel() - 1
+        cap = int(lib().spx_digest_capacity(kind, k, total_chars))
+        d_out = torch.empty(cap, dtype=torch.uint8, device=d_seqs.device)
+        d_out_offs = torch.empty(nreads + 1, dtype=torch.int64, device=d_seqs.device)
+        _check(lib().spx_digest_batch_device(self._h, kind, k, w, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars,
+                                             _t_ptr(d_out), cap, _t_ptr(d_out_offs), C.c_void_p(st.cuda_stream)))
+        return d_out, d_out_offs
+
+    def digest_query_host(self, mode, kind, k, w, seqs, offs, want_lengths=True, want_docs=False, classify=None):
+        """digest + query in one call (the reference's per-read loop body, for a batch)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        nreads = offs.size - 1
+        tot = int(offs[-1]) if nreads > 0 else 0
+        cap = int(lib().spx_digest_capacity(kind, k, tot))
+        out_offs = np.zeros(nreads + 1, dtype=np.uint64)
+        lens = np.zeros(cap, dtype=np.uint32) if want_lengths else None
+        ptrs = np.zeros(cap, dtype=np.uint64) if mode == SPX_MODE_MS else None
+        docs = np.zeros(cap, dtype=np.uint32) if want_docs else None
+        cls_ = np.zeros(max(nreads, 1), dtype=CLASS_DTYPE) if classify else None
+        bw, thr = classify if classify else (0, 0)
+        _check(lib().spx_digest_query_batch(self._h, mode, kind, k, w, _np_ptr(seqs), _np_ptr(offs), nreads,
+                                            _np_ptr(out_offs), cap, _np_ptr(lens), _np_ptr(ptrs), _np_ptr(docs),
+                                            _np_ptr(cls_), bw, thr))
+        dt = int(out_offs[-1])
+        out = {"offsets": out_offs}
+        if lens is not None:
+            out["lengths"] = lens[:dt]
+        if ptrs is not None:
+            out["pointers"] = ptrs[:dt]
+        if docs is not None:
+            out["docs"] = docs[:dt]
+        if cls_ is not None:
+            out["class"] = cls_[:nreads]
+        return out
 
     def last_stats(self) -> dict:
         s = SpxWalkStats()

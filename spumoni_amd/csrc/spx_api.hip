@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <random>
 #include <vector>
 
 #include "spx_internal.h"
@@ -162,6 +163,18 @@ static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* l
     return SPX_OK;
 }
 
+// bonsai's RollingHasher draws its character table from a Mersenne twister seeded with 1337
+// and keeps 8 bits (our reading of CharacterHash): entry c = c-th output
+static void default_charhash(uint8_t out[4]) {
+    std::mt19937 gen(1337u);
+    uint8_t table[256];
+    for (int c = 0; c < 256; ++c) table[c] = (uint8_t)(gen() & 0xffu);
+    out[0] = table['A'];
+    out[1] = table['C'];
+    out[2] = table['G'];
+    out[3] = table['T'];
+}
+
 spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr,
                                uint64_t r, const uint64_t* ssa, const uint64_t* esa,
                                const uint64_t* doc_start, const uint64_t* doc_end, int where,
@@ -173,6 +186,7 @@ spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const
     }
     spx_index* ix = new spx_index();
     ix->device = device;
+    default_charhash(ix->charhash);
     if (from_runs_impl(ix, heads, lens, thr, r, ssa, esa, doc_start, doc_end, where) != SPX_OK) {
         spx_index_free(ix);
         return nullptr;
@@ -291,8 +305,85 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->force_lanes_per_wave = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "minimizer_charhash")) {
+        for (int c = 0; c < 4; ++c) ix->charhash[c] = (uint8_t)((uint64_t)value >> (8 * c));
+        return SPX_OK;
+    }
     set_error("unknown option '%s'", key);
     return SPX_E_ARG;
+}
+
+uint64_t spx_digest_capacity(int kind, uint32_t k, uint64_t total_chars) {
+    // every k-mer can be reported once: <= total_chars values of 1 byte (-m) or k bytes (-a);
+    // + the padding spx_query_batch_device asks of its d_seqs
+    const uint64_t body = (kind == SPX_DIGEST_DNA ? (uint64_t)(k ? k : 1) : 1ull) * total_chars;
+    return ((body + 3) / 4) * 4 + 32;
+}
+
+int spx_digest_batch_device(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs,
+                            const uint64_t* d_offsets, uint64_t nreads, uint64_t total_chars,
+                            uint8_t* d_out_seqs, uint64_t out_capacity, uint64_t* d_out_offsets, void* stream) {
+    if (!ix || !d_seqs || !d_offsets || !d_out_seqs || !d_out_offsets) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    if (out_capacity < spx_digest_capacity(kind, k, total_chars)) {
+        set_error("d_out_seqs must hold spx_digest_capacity() = %llu bytes",
+                  (unsigned long long)spx_digest_capacity(kind, k, total_chars));
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    return launch_digest(ix, kind, k, w, d_seqs, d_offsets, nreads, d_out_seqs, d_out_offsets, st);
+}
+
+// grow-only device scratch owned by the index (no hipMalloc/hipFree per call); callers hold host_mu
+static int ensure_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
+    spx_index::Scratch& sc = ix->scratch[slot];
+    if (sc.cap < bytes) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr;
+        sc.cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        SPX_HIP(hipMalloc(&sc.p, want));
+        sc.cap = want;
+    }
+    *out = sc.p;
+    return SPX_OK;
+}
+
+int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* seqs, const uint64_t* offsets,
+                     uint64_t nreads, uint8_t* out_seqs, uint64_t out_capacity, uint64_t* out_offsets) {
+    if (!ix || !seqs || !offsets || !out_offsets) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> hg(ix->host_mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    const uint64_t total = nreads ? offsets[nreads] : 0;
+    const uint64_t cap = spx_digest_capacity(kind, k, total);
+    void *dseq = nullptr, *doff = nullptr, *dout = nullptr, *dooff = nullptr;
+    int rc;
+    if ((rc = ensure_scratch(ix, 6, total + 16, &dseq)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 0, cap, &dout)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    rc = spx_digest_batch_device(ix, kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total,
+                                 (uint8_t*)dout, cap, (uint64_t*)dooff, nullptr);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipDeviceSynchronize());
+    SPX_HIP(hipMemcpy(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost));
+    const uint64_t dtotal = out_offsets[nreads];
+    if (dtotal > out_capacity || (dtotal && !out_seqs)) {
+        set_error("out_seqs holds %llu bytes, the digested reads need %llu", (unsigned long long)out_capacity,
+                  (unsigned long long)dtotal);
+        return SPX_E_ARG;
+    }
+    if (dtotal) SPX_HIP(hipMemcpy(out_seqs, dout, dtotal, hipMemcpyDeviceToHost));
+    return SPX_OK;
 }
 
 static int check_query(spx_index* ix, int mode, const void* seqs, const void* offs,
@@ -395,6 +486,35 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     return SPX_OK;
 }
 
+// device side of the host-buffer queries: d_seq / d_off are resident (scratch), results go
+// through scratch slots 2..5 to the host buffers.  Caller holds host_mu.
+static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const uint64_t* d_off, uint64_t nreads,
+                         uint64_t total, uint32_t* out_lengths, uint64_t* out_pointers, uint32_t* out_docs,
+                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr) {
+    void *dlen = nullptr, *dptr = nullptr, *ddoc = nullptr, *dcls = nullptr;
+    int rc;
+    if (out_lengths && (rc = ensure_scratch(ix, 2, (total + 1) * 4, &dlen)) != SPX_OK) return rc;
+    if (out_pointers && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &dptr)) != SPX_OK) return rc;
+    if (out_docs && (rc = ensure_scratch(ix, 4, (total + 1) * 4, &ddoc)) != SPX_OK) return rc;
+    if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
+    rc = spx_query_batch_device(ix, mode, d_seq, d_off, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr,
+                                (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipDeviceSynchronize());
+    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen, total * 4, hipMemcpyDeviceToHost));
+    if (out_pointers) SPX_HIP(hipMemcpy(out_pointers, dptr, total * 8, hipMemcpyDeviceToHost));
+    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc, total * 4, hipMemcpyDeviceToHost));
+    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    if (wc.error) {
+        set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
+                  "thresholds are inconsistent with the BWT)", wc.error);
+        return SPX_E_FORMAT;
+    }
+    return SPX_OK;
+}
+
 int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
                     uint64_t nreads, uint32_t* out_lengths, uint64_t* out_pointers,
                     uint32_t* out_docs, spx_class* out_class, uint64_t bin_width,
@@ -405,50 +525,51 @@ int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t
     std::lock_guard<std::mutex> hg(ix->host_mu);  // one host-buffer query at a time per index
     SPX_HIP(hipSetDevice(ix->device));
     const uint64_t total = nreads ? offsets[nreads] : 0;
-    // grow-only device scratch owned by the index (no hipMalloc/hipFree per call)
-    struct Ref {
-        void* p;
-    } dseq{nullptr}, doff{nullptr}, dlen{nullptr}, dptr{nullptr}, ddoc{nullptr}, dcls{nullptr};
-    auto ensure = [&](int slot, size_t bytes, void** out) -> int {
-        spx_index::Scratch& sc = ix->scratch[slot];
-        if (sc.cap < bytes) {
-            if (sc.p) (void)hipFree(sc.p);
-            sc.p = nullptr;
-            sc.cap = 0;
-            const size_t want = bytes + bytes / 4 + 256;
-            SPX_HIP(hipMalloc(&sc.p, want));
-            sc.cap = want;
-        }
-        *out = sc.p;
-        return SPX_OK;
-    };
+    void *dseq = nullptr, *doff = nullptr;
     const uint64_t padded = ((total + 3) / 4) * 4 + 32;
-    if ((rc = ensure(0, padded, &dseq.p)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(dseq.p, seqs, total, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemset((char*)dseq.p + total, 0, padded - total));
-    if ((rc = ensure(1, (nreads + 1) * 8, &doff.p)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(doff.p, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
-    if (out_lengths && (rc = ensure(2, (total + 1) * 4, &dlen.p)) != SPX_OK) return rc;
-    if (out_pointers && (rc = ensure(3, (total + 1) * 8, &dptr.p)) != SPX_OK) return rc;
-    if (out_docs && (rc = ensure(4, (total + 1) * 4, &ddoc.p)) != SPX_OK) return rc;
-    if (out_class && (rc = ensure(5, (nreads + 1) * sizeof(spx_class), &dcls.p)) != SPX_OK) return rc;
-    rc = spx_query_batch_device(ix, mode, (const uint8_t*)dseq.p, (const uint64_t*)doff.p, nreads,
-                                total, (uint32_t*)dlen.p, (uint64_t*)dptr.p, (uint32_t*)ddoc.p,
-                                (spx_class*)dcls.p, bin_width, max_value_thr, nullptr);
+    if ((rc = ensure_scratch(ix, 0, padded, &dseq)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemset((char*)dseq + total, 0, padded - total));
+    if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
+                         out_pointers, out_docs, out_class, bin_width, max_value_thr);
+}
+
+int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* seqs,
+                           const uint64_t* offsets, uint64_t nreads, uint64_t* out_offsets, uint64_t out_capacity,
+                           uint32_t* out_lengths, uint64_t* out_pointers, uint32_t* out_docs, spx_class* out_class,
+                           uint64_t bin_width, uint64_t max_value_thr) {
+    int rc = check_query(ix, mode, seqs, offsets, out_lengths, out_pointers, out_docs, out_class, bin_width);
     if (rc != SPX_OK) return rc;
-    SPX_HIP(hipDeviceSynchronize());
-    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen.p, total * 4, hipMemcpyDeviceToHost));
-    if (out_pointers) SPX_HIP(hipMemcpy(out_pointers, dptr.p, total * 8, hipMemcpyDeviceToHost));
-    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc.p, total * 4, hipMemcpyDeviceToHost));
-    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls.p, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
-    WalkCounters wc;
-    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
-    if (wc.error) {
-        set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
-                  "thresholds are inconsistent with the BWT)", wc.error);
-        return SPX_E_FORMAT;
+    if (!out_offsets) {
+        set_error("out_offsets must be non-null");
+        return SPX_E_ARG;
     }
-    return SPX_OK;
+    std::lock_guard<std::mutex> hg(ix->host_mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    const uint64_t total = nreads ? offsets[nreads] : 0;
+    const uint64_t cap = spx_digest_capacity(kind, k, total);
+    void *draw = nullptr, *doff = nullptr, *dseq = nullptr, *dooff = nullptr;
+    if ((rc = ensure_scratch(ix, 6, total + 16, &draw)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 0, cap, &dseq)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(draw, seqs, total, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    rc = spx_digest_batch_device(ix, kind, k, w, (const uint8_t*)draw, (const uint64_t*)doff, nreads, total,
+                                 (uint8_t*)dseq, cap, (uint64_t*)dooff, nullptr);
+    if (rc != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost));  // synchronises
+    const uint64_t dtotal = out_offsets[nreads];
+    if (dtotal > out_capacity) {
+        set_error("output buffers hold %llu entries, the digested reads have %llu characters",
+                  (unsigned long long)out_capacity, (unsigned long long)dtotal);
+        return SPX_E_ARG;
+    }
+    // the digested reads never leave the device: the walk starts from the scratch buffers
+    return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)dooff, nreads, dtotal, out_lengths,
+                         out_pointers, out_docs, out_class, bin_width, max_value_thr);
 }
 
 int spx_last_walk_stats(spx_index* ix, spx_walk_stats* out) {

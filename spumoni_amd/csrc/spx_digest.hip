@@ -1,0 +1,197 @@
+// spx_digest.hip -- minimizer digestion of a read batch on the device: the pre-step of
+// `spumoni run -m` (perform_minimizer_digestion, src/spumoni.cpp:294-319) and `run -a`
+// (perform_dna_minimizer_digestion, :321-342), which the reference runs read by read on the
+// host before matching_statistics (src/compute_ms_pml.cpp:919-923).
+//
+// What is computed (the minimizer streams are bonsai's, dnbaker/bonsai @5273b81a92, absent
+// offline -- the assumptions are listed in DESIGN.md section 4.4 and oracle/orc_digest.c):
+//   * k-mers of the read over ACGT (k <= 4, include/spumoni_main.hpp:316); a character
+//     outside ACGT restarts the k-mer and contributes nothing else;
+//   * value of a k-mer: -m  its 8-bit cyclic-polynomial hash  XOR_j rotl8(T[c_j], k-1-j)
+//                       -a  its 2-bit code (A0 C1 G2 T3, first base most significant),
+//                           ordered by  code ^ XOR_MASK;
+//   * the stream of k-mers goes through a window of wsz = w-k+1 entries: from the wsz-th
+//     k-mer on, every k-mer reports the least value of the last wsz;
+//   * the caller's lambda drops a report equal to the previous one (:305, :333) and writes
+//     -m the byte `x > 2 ? x : x + 3` (:311) / -a the k letters of the k-mer (:336).
+//
+// Mapping: one wavefront per read, 64 positions per iteration, byte work only -- HBM-bound
+// streaming (read the characters twice, write ~0.2 bytes per character).  The k-mer stream,
+// the window minima and the emitted bytes of one iteration are positioned with ballots +
+// popcounts; the last wsz-1 stream entries and the last minimum are carried in an LDS ring.
+// Two launches: count -> exclusive scan (hipCUB) -> write, so that the digested reads come out
+// concatenated with an offsets array, which is what the walk kernel takes.
+#include <hipcub/hipcub.hpp>
+
+#include "spx_internal.h"
+
+namespace spx {
+namespace {
+
+constexpr uint64_t LEX_XOR_MASK = 0xe37e28c4271b5a2dULL;  // bonsai's XOR_MASK (from Kraken)
+
+struct DigestArgs {
+    const uint8_t* seqs;
+    const uint64_t* offs;
+    uint64_t nreads;
+    uint32_t kind;  // SPX_DIGEST_PROMOTED / SPX_DIGEST_DNA
+    uint32_t k;
+    uint32_t wsz;   // k-mers per window
+    uint32_t ring;  // power of two >= wsz + 64
+    uint32_t xm;    // LEX_XOR_MASK restricted to the 2k bits of a k-mer
+    uint8_t key_of_kmer[256];  // sort key of every k-mer code: the hash (-m) or code ^ xm (-a)
+    uint64_t* counts;          // pass 0: counts[q + 1] = bytes read q digests to
+    const uint64_t* out_offs;  // pass 1
+    uint8_t* out;
+};
+
+__device__ __forceinline__ int base_code(uint32_t c) {
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(64) k_digest(const DigestArgs a) {
+    extern __shared__ uint8_t lds[];
+    uint8_t* const keys = lds;            // ring of stream keys
+    uint8_t* const mins = lds + a.ring;   // ring of window minima, by stream index
+    uint8_t* const lut = lds + 2 * a.ring;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) lut[i] = a.key_of_kmer[i];
+    __syncthreads();
+    const uint32_t rmask = a.ring - 1;
+    const uint32_t k = a.k, wsz = a.wsz;
+    const uint64_t lt = (1ull << lane) - 1;
+    for (uint64_t rd = blockIdx.x; rd < a.nreads; rd += gridDim.x) {
+        const uint64_t base = a.offs[rd];
+        const uint64_t len = a.offs[rd + 1] - base;
+        uint64_t ob = 0;
+        if (PASS == 1) ob = a.out_offs[rd];
+        uint64_t t_base = 0;  // k-mers streamed so far
+        uint64_t e_base = 0;  // values emitted so far
+        uint64_t prev_valid = 0;
+        uint32_t prev_code = 0;
+        for (uint64_t p0 = 0; p0 < len; p0 += 64) {
+            const uint64_t p = p0 + lane;
+            const uint32_t code = p < len ? (uint32_t)base_code(a.seqs[base + p]) : 4u;
+            const uint64_t valid = __ballot(code < 4);
+            // k-mer ending at p: the k characters p-k+1 .. p must all be ACGT
+            uint64_t kv = valid;
+            uint32_t kmer = code & 3;
+            for (uint32_t j = 1; j < k; ++j) {
+                kv &= (valid << j) | (prev_valid >> (64 - j));
+                const uint32_t up = __shfl_up(code, j), carry = __shfl(prev_code, (int)(64 + lane - j) & 63);
+                kmer |= ((lane >= j ? up : carry) & 3) << (2 * j);
+            }
+            const bool has = (kv >> lane) & 1;
+            const uint64_t t = t_base + __popcll(kv & lt);
+            if (has) keys[t & rmask] = lut[kmer];
+            __syncthreads();
+            const bool reports = has && t + 1 >= wsz;
+            uint32_t mn = 0xffffffffu;
+            if (reports) {
+                for (uint32_t j = 0; j < wsz; ++j) mn = min(mn, (uint32_t)keys[(t - j) & rmask]);
+                mins[t & rmask] = (uint8_t)mn;
+            }
+            __syncthreads();
+            // mseq_vec.empty() || mseq_vec.back() != x   (values are < 256: the uint8_t vector
+            // compares exactly)
+            const bool emit = reports && (t + 1 == wsz || mins[(t - 1) & rmask] != mn);
+            const uint64_t em = __ballot(emit);
+            if (PASS == 1 && emit) {
+                const uint64_t e = e_base + __popcll(em & lt);
+                if (a.kind == SPX_DIGEST_PROMOTED) {
+                    a.out[ob + e] = (uint8_t)(mn > 2 ? mn : mn + 3);
+                } else {
+                    const uint32_t code_min = mn ^ a.xm;
+                    for (uint32_t j = 0; j < k; ++j)
+                        a.out[ob + e * k + j] = (uint8_t)"ACGT"[(code_min >> (2 * (k - 1 - j))) & 3];
+                }
+            }
+            t_base += __popcll(kv);
+            e_base += __popcll(em);
+            prev_valid = valid;
+            prev_code = code;
+            __syncthreads();
+        }
+        if (PASS == 0 && lane == 0) a.counts[rd + 1] = e_base * (a.kind == SPX_DIGEST_DNA ? k : 1);
+    }
+}
+
+// the walk reads its characters in aligned 32-byte windows past the last read: define the tail
+__global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* out) {
+    const uint64_t total = out_offs[nreads];
+    const uint64_t end = ((total + 3) / 4) * 4 + 32;
+    for (uint64_t i = total + threadIdx.x; i < end; i += blockDim.x) out[i] = 0;
+}
+
+}  // namespace
+
+int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
+                  uint64_t nreads, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st) {
+    if (kind != SPX_DIGEST_PROMOTED && kind != SPX_DIGEST_DNA) {
+        set_error("digest kind must be SPX_DIGEST_PROMOTED (-m) or SPX_DIGEST_DNA (-a)");
+        return SPX_E_ARG;
+    }
+    if (k < 1 || k > 4) {  // include/spumoni_main.hpp:316
+        set_error("small window size (k) must be in [1, 4]");
+        return SPX_E_ARG;
+    }
+    if (w < k) {  // :317
+        set_error("large window size (w) should be at least the small window size (k)");
+        return SPX_E_ARG;
+    }
+    DigestArgs a;
+    a.seqs = d_seqs;
+    a.offs = d_offs;
+    a.nreads = nreads;
+    a.kind = (uint32_t)kind;
+    a.k = k;
+    a.wsz = w - k + 1;
+    if (a.wsz > 16384u - 64) {
+        set_error("large window size (w) beyond %u is not supported by the device digestion", 16384u - 64 + k - 1);
+        return SPX_E_UNSUPPORTED;
+    }
+    uint32_t ring = 128;
+    while (ring < a.wsz + 64) ring <<= 1;
+    a.ring = ring;
+    a.xm = (uint32_t)(LEX_XOR_MASK & ((1ull << (2 * k)) - 1));
+    for (uint32_t code = 0; code < 256; ++code) {
+        if (kind == SPX_DIGEST_DNA) {
+            a.key_of_kmer[code] = (uint8_t)((code ^ a.xm) & 0xff);
+        } else {
+            // CyclicHash<uint8_t>, word size 8, over the k characters, first character first
+            uint8_t h = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint32_t c = (code >> (2 * (k - 1 - j))) & 3;
+                h = (uint8_t)(((h << 1) | (h >> 7)) ^ ix->charhash[c]);
+            }
+            a.key_of_kmer[code] = h;
+        }
+    }
+    a.counts = d_out_offs;
+    a.out_offs = d_out_offs;
+    a.out = d_out;
+    SPX_HIP(hipMemsetAsync(d_out_offs, 0, 8, st));
+    if (nreads == 0) {
+        k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, 0, d_out);
+        return SPX_OK;
+    }
+    const size_t lds = 2 * (size_t)ring + 256;
+    const uint64_t max_blocks = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256) * 64;
+    const uint32_t grid = (uint32_t)(nreads < max_blocks ? nreads : max_blocks);
+    k_digest<0><<<grid, 64, lds, st>>>(a);
+    SPX_HIP(hipGetLastError());
+    // counts -> offsets, in place
+    size_t tmp_bytes = 0;
+    SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
+    void* tmp = nullptr;
+    SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+    SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
+    SPX_HIP(hipFreeAsync(tmp, st));
+    k_digest<1><<<grid, 64, lds, st>>>(a);
+    k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
+    SPX_HIP(hipGetLastError());
+    return SPX_OK;
+}
+
+}  // namespace spx

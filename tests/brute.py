@@ -63,3 +63,47 @@ def select_brute(bwt, i, c):
                 return p
             cnt += 1
     raise IndexError
+
+
+# ---------------------------------------------------------------------------------------------
+# minimizer digestion, written as a specification (slices and min(), no queue): what
+# oracle/orc_digest.c and the HIP kernel must both produce.  See DESIGN.md 4.4 for the
+# assumptions about bonsai this encodes.
+LEX_XOR_MASK = 0xE37E28C4271B5A2D
+
+
+def digest_spec(kind, k, w, seq: bytes, charhash):
+    """kind 1: -m (promoted), kind 2: -a (DNA letters).  charhash: T[A], T[C], T[G], T[T]."""
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    wsz = max(1, w - k + 1)
+
+    def rotl8(x, s):
+        s %= 8
+        return ((x << s) | (x >> (8 - s))) & 0xFF if s else x
+
+    stream = []  # (score, element) of every k-mer made of ACGT only, in read order
+    for i in range(k - 1, len(seq)):
+        win = seq[i - k + 1 : i + 1]
+        if any(c not in code for c in win):
+            continue
+        if kind == 2:
+            km = 0
+            for c in win:
+                km = km * 4 + code[c]
+            stream.append((km ^ LEX_XOR_MASK, km))
+        else:
+            h = 0
+            for j, c in enumerate(win):
+                h ^= rotl8(charhash[code[c]], k - 1 - j)
+            stream.append((h, h))
+    reports = [min(stream[t - wsz + 1 : t + 1])[1] for t in range(wsz - 1, len(stream))]
+    out = bytearray()
+    last = None
+    for x in reports:
+        if last is None or (last & 0xFF) != x:  # mseq_vec is a vector<uint8_t>
+            last = x
+            if kind == 2:
+                out += bytes("ACGT"[(x >> (2 * (k - 1 - j))) & 3].encode()[0] for j in range(k))
+            else:
+                out.append(x if x > 2 else x + 3)
+    return bytes(out)
