@@ -227,8 +227,12 @@ int main(int argc, char **argv) {
     const int use_promotions = argv[7][0] == 'm', use_dna_letters = argv[7][0] == 'a';
     const char *text_path = (argc > 8 && argv[8][0] != '-') ? argv[8] : NULL;
     int dump_reads = 0;
-    for (int i = 8; i < argc; ++i)
+    unsigned dig_k = 4, dig_w = 11; /* include/spumoni_main.hpp:247-248 */
+    for (int i = 8; i < argc; ++i) {
         if (!strcmp(argv[i], "--dump-reads")) dump_reads = 1;
+        if (!strcmp(argv[i], "--k") && i + 1 < argc) dig_k = (unsigned)atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--w") && i + 1 < argc) dig_w = (unsigned)atoi(argv[i + 1]);
+    }
     char path[4096];
 
     size_t fsz = 0;
@@ -296,20 +300,37 @@ int main(int argc, char **argv) {
                 max_value_thr, "):", "above thr:", "below thr:");
     }
 
-    str id = {0}, seq = {0};
+    str id = {0}, seq = {0}, seq_view = {0};
+    char *dig = NULL;
+    size_t dig_cap = 0;
     uint64_t *lengths = NULL, *pointers = NULL, *docs = NULL;
     size_t cap = 0, num_reads = 0;
     while (loadBatch(&L, &input, 1000)) { /* :903 */
         while (grabNextRead(&L, &id, &seq)) {
             for (size_t i = 0; i < seq.n; ++i) seq.p[i] = (char)toupper((unsigned char)seq.p[i]); /* :917 */
-            if (seq.n == 0) { /* :926-931 */
+            if (use_promotions || use_dna_letters) { /* :920-923 */
+                const size_t dcap = (size_t)dig_k * seq.n + 1;
+                if (dcap > dig_cap) {
+                    dig_cap = 2 * dcap;
+                    dig = (char *)realloc(dig, dig_cap);
+                }
+                const size_t dn = orc_digest(use_promotions ? ORC_DIGEST_PROMOTED : ORC_DIGEST_DNA, dig_k, dig_w, NULL,
+                                             (const uint8_t *)seq.p, seq.n, (uint8_t *)dig, dcap);
+                dig[dn] = 0;
+                seq_view.p = dig;
+                seq_view.n = dn;
+            } else {
+                seq_view = seq;
+            }
+            const str rd = seq_view; /* the read as searched */
+            if (rd.n == 0) { /* :926-931 */
                 printf("\n\n");
                 fprintf(stderr, "Warning: %s was empty after digestion, commonly due to reads "
                                 "consisting of mostly non-ACGT characters. Please remove "
                                 "read or run SPUMONI without minimizer digestion.\n\n", id.p);
                 exit(1);
             }
-            const size_t m = seq.n;
+            const size_t m = rd.n;
             if (m > cap) {
                 cap = 2 * m;
                 lengths = (uint64_t *)realloc(lengths, cap * 8);
@@ -318,15 +339,15 @@ int main(int argc, char **argv) {
             }
             if (!is_ms) {
                 if (use_doc)
-                    orc_pml_query_doc(ix, seq.p, m, lengths, docs);
+                    orc_pml_query_doc(ix, rd.p, m, lengths, docs);
                 else
-                    orc_pml_query(ix, seq.p, m, lengths);
+                    orc_pml_query(ix, rd.p, m, lengths);
             } else {
                 if (use_doc)
-                    orc_ms_query_doc(ix, seq.p, m, pointers, docs);
+                    orc_ms_query_doc(ix, rd.p, m, pointers, docs);
                 else
-                    orc_ms_query(ix, seq.p, m, pointers);
-                orc_ms_lengths(seq.p, m, pointers, text, n_text, lengths);
+                    orc_ms_query(ix, rd.p, m, pointers);
+                orc_ms_lengths(rd.p, m, pointers, text, n_text, lengths);
             }
             uint64_t above = 0, below = 0, sum = 0;
             int found = 0;

@@ -101,7 +101,17 @@ def main(argv=None):
     ap.add_argument("--no-rev-comp", action="store_true")
     ap.add_argument("--doc", action="store_true", help="also write the document array")
     ap.add_argument("--null-reads", type=int, default=800)
+    ap.add_argument("-m", "--minimizer-alphabet", action="store_true",
+                    help="index the promoted-minimizer digestion of every sequence (files named <prefix>.bin*)")
+    ap.add_argument("-a", "--dna-minimizer", action="store_true",
+                    help="index the DNA-letter minimizer digestion of every sequence")
+    ap.add_argument("-K", "--small-window", type=int, default=4)
+    ap.add_argument("-W", "--large-window", type=int, default=11)
     a = ap.parse_args(argv)
+    if a.minimizer_alphabet and a.dna_minimizer:
+        ap.error("only one of -m / -a")
+    digest_kind = capi.SPX_DIGEST_PROMOTED if a.minimizer_alphabet else capi.SPX_DIGEST_DNA if a.dna_minimizer else 0
+    digester = capi.digester(0) if digest_kind else None
     files = [a.ref] if a.ref else [ln.split()[0] for ln in open(a.filelist) if ln.strip()]
     if not files:
         ap.error("give -r or -l")
@@ -111,6 +121,10 @@ def main(argv=None):
         for s in read_fasta(fpath):
             pieces = [s] if a.no_rev_comp else [s, synth.revcomp(s)]
             for p in pieces:
+                if digester is not None:  # every sequence is digested on its own, like a read
+                    p, _ = digester.digest_host(digest_kind, a.small_window, a.large_window, p,
+                                                np.array([0, p.size], dtype=np.uint64))
+                    p = p.copy()
                 parts.append(p)
                 total += p.size
         doc_lengths.append(total)
@@ -119,7 +133,7 @@ def main(argv=None):
         sys.exit("the text contains bytes 0/1, which are reserved for the terminator")
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     raw = synth.index_from_text(torch.from_numpy(text).to(dev), doc_lengths=doc_lengths).cpu()
-    prefix = a.output + ".fa"
+    prefix = a.output + (".bin" if a.minimizer_alphabet else ".fa")  # src/spumoni.cpp:744-747
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     with open(prefix, "wb") as f:
         f.write(b">concatenated\n" + text.tobytes() + b"\n")

@@ -302,6 +302,17 @@ class Index:
         return {f[0]: getattr(s, f[0]) for f in SpxWalkStats._fields_}
 
 
+def digester(device: int = 0) -> "Index":
+    """A minimal index handle, for callers that only want the device digestion (index builders)."""
+    import torch
+
+    from .synth import RawIndex
+
+    z = torch.zeros(1, dtype=torch.int64)
+    return Index.from_raw(RawIndex(heads=torch.zeros(1, dtype=torch.uint8), lens=torch.ones(1, dtype=torch.int64),
+                                   thr=z, n=1), device)
+
+
 def pinned_array(shape, dtype):
     """numpy array backed by spx_host_alloc (page-locked) memory; keep the returned owner alive."""
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize

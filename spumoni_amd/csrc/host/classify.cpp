@@ -155,16 +155,26 @@ struct Results {
     PinnedBuf<uint32_t> lengths, docs;
     PinnedBuf<uint64_t> pointers;
     PinnedBuf<spx_class> cls;
+    // results of read q are entries [beg[q], end[q]) of the arrays above: the read's own
+    // offsets, or -- with -m / -a -- the offsets of the digested read
+    std::vector<uint64_t> beg, end;
 };
 
 // contiguous, character-balanced shards: one per device, run concurrently
 void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
     const size_t nreads = sb.nreads();
     const uint64_t total = sb.offs.back();
-    res.lengths.resize_uninit(total);
-    if (o.ms) res.pointers.resize_uninit(total);
-    if (o.use_doc) res.docs.resize_uninit(total);
+    const bool digest = o.use_promotions || o.use_dna_letters;
+    const int kind = o.use_promotions ? SPX_DIGEST_PROMOTED : SPX_DIGEST_DNA;
+    // with digestion a shard's results are laid out at the digested offsets, inside a region as
+    // large as its worst case (every k-mer reported: 1 byte each for -m, k letters for -a)
+    const uint64_t grow = digest && o.use_dna_letters ? (uint64_t)o.k : 1;
+    res.lengths.resize_uninit(total * grow);
+    if (o.ms) res.pointers.resize_uninit(total * grow);
+    if (o.use_doc) res.docs.resize_uninit(total * grow);
     if (o.write_report) res.cls.resize_uninit(nreads);
+    res.beg.resize(nreads);
+    res.end.resize(nreads);
     const size_t ndev = set.ix.size();
     std::vector<size_t> cut(ndev + 1, nreads);
     cut[0] = 0;
@@ -180,10 +190,33 @@ void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, si
         const uint64_t a = sb.offs[lo];
         std::vector<uint64_t> offs(hi - lo + 1);
         for (size_t q = lo; q <= hi; ++q) offs[q - lo] = sb.offs[q] - a;
-        int rc = spx_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data() + a, offs.data(),
-                                 hi - lo, res.lengths.data() + a, o.ms ? res.pointers.data() + a : nullptr,
-                                 o.use_doc ? res.docs.data() + a : nullptr,
+        const uint64_t ra = a * grow;  // where this shard's results start
+        int rc;
+        if (!digest) {
+            rc = spx_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data() + a, offs.data(),
+                                 hi - lo, res.lengths.data() + ra, o.ms ? res.pointers.data() + ra : nullptr,
+                                 o.use_doc ? res.docs.data() + ra : nullptr,
                                  o.write_report ? res.cls.data() + lo : nullptr, o.bin_size, max_value_thr);
+            for (size_t q = lo; q < hi; ++q) {
+                res.beg[q] = sb.offs[q];
+                res.end[q] = sb.offs[q + 1];
+            }
+        } else {
+            // perform_minimizer_digestion / perform_dna_minimizer_digestion + matching_statistics
+            // (compute_ms_pml.cpp:919-938), the batch on the device in one call
+            std::vector<uint64_t> doffs(hi - lo + 1);
+            rc = spx_digest_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, kind, (uint32_t)o.k,
+                                        (uint32_t)o.w, sb.seqs.data() + a, offs.data(), hi - lo, doffs.data(),
+                                        (sb.offs[hi] - a) * grow, res.lengths.data() + ra,
+                                        o.ms ? res.pointers.data() + ra : nullptr,
+                                        o.use_doc ? res.docs.data() + ra : nullptr,
+                                        o.write_report ? res.cls.data() + lo : nullptr, o.bin_size, max_value_thr);
+            if (rc == SPX_OK)
+                for (size_t q = lo; q < hi; ++q) {
+                    res.beg[q] = ra + doffs[q - lo];
+                    res.end[q] = ra + doffs[q - lo + 1];
+                }
+        }
         if (rc != SPX_OK) errors[d] = spx_last_error();
     };
     std::vector<std::thread> th;
@@ -209,7 +242,7 @@ void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res,
                   TextChunk& out) {
     std::ostringstream rep;
     for (size_t q = lo; q < hi; ++q) {
-        const uint64_t a = sb.offs[q], b = sb.offs[q + 1];
+        const uint64_t a = res.beg[q], b = res.end[q];
         if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
             out.td.header(sb.ids[q]);
             for (uint64_t i = a; i < b; ++i) out.td.u64(res.docs[i]);
@@ -347,16 +380,6 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
     // where does every thread's part go, and where is the first problem (if any)?
     std::vector<size_t> take(nt, 0), chars(nt, 0);
     for (size_t t = 0; t < nt && !slot.deferred; ++t) {
-        if (o.use_promotions || o.use_dna_letters) {
-            if (!parsed[t].empty()) {
-                slot.deferred = 1;
-                slot.deferred_msg =
-                    "minimizer digestion of reads (-m / -a) is not available in this build: the\n"
-                    "       reference delegates it to dnbaker/bonsai, whose source is not available offline\n"
-                    "       (DESIGN.md). Digest the reads beforehand and run with -n.";
-            }
-            break;
-        }
         for (const ParsedRead& rd : parsed[t]) {
             if (rd.seq.empty()) {  // :926-931
                 slot.deferred = 2;
@@ -440,6 +463,19 @@ size_t classify_reads(IndexSet& set, const RunOptions& o) {
             if (i < 0) break;
             t_gpu.start();
             if (slots[i].sb.nreads() > 0) run_on_devices(set, o, slots[i].sb, max_value_thr, slots[i].res);
+            if (o.use_promotions || o.use_dna_letters) {
+                // a read that digests to nothing is fatal where the reference meets it (:926-931):
+                // everything before it is still written
+                Slot& s = slots[i];
+                for (size_t q = 0; q < s.sb.nreads(); ++q)
+                    if (s.res.beg[q] == s.res.end[q]) {
+                        s.deferred = 2;
+                        s.deferred_msg = s.sb.ids[q];
+                        s.sb.ids.resize(q);
+                        s.sb.offs.resize(q + 1);
+                        break;
+                    }
+            }
             t_gpu.stop();
             computed_q.push(i);
         }

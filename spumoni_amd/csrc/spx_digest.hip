@@ -4,7 +4,7 @@
 // host before matching_statistics (src/compute_ms_pml.cpp:919-923).
 //
 // What is computed (the minimizer streams are bonsai's, dnbaker/bonsai @5273b81a92, absent
-// offline -- the assumptions are listed in DESIGN.md section 4.4 and oracle/orc_digest.c):
+// offline -- the assumptions are listed in DESIGN.md section 4.4):
 //   * k-mers of the read over ACGT (k <= 4, include/spumoni_main.hpp:316); a character
 //     outside ACGT restarts the k-mer and contributes nothing else;
 //   * value of a k-mer: -m  its 8-bit cyclic-polynomial hash  XOR_j rotl8(T[c_j], k-1-j)

@@ -53,7 +53,7 @@ def _setup(tmp_path, seed, letters, n=6000, nreads=300):
     return ref, prefix, seqs, offs, rng
 
 
-def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, fastq=False):
+def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, fastq=False, digest="n", kw=()):
     a_dir, b_dir = tmp_path / "gpu", tmp_path / "orc"
     for d in (a_dir, b_dir):
         shutil.rmtree(d, ignore_errors=True)
@@ -61,15 +61,19 @@ def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, f
     _write_fasta(a_dir / reads_name, seqs, offs, np.random.default_rng(77), fastq)
     shutil.copy(a_dir / reads_name, b_dir / reads_name)
     env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext")
-    cmd = [HOST_BIN, "run", "-r", ref, "-p", str(a_dir / reads_name), "-n", mode] + flags
+    cmd = [HOST_BIN, "run", "-r", ref, "-p", str(a_dir / reads_name), "-" + digest, mode] + flags
+    orc_kw = []
+    if kw:
+        cmd += ["-K", str(kw[0]), "-W", str(kw[1])]
+        orc_kw = ["--k", str(kw[0]), "--w", str(kw[1])]
     r = subprocess.run(cmd, capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()
     assert b"finished processing" in r.stderr
     doc = "1" if "-d" in flags else "0"
     rep = "1" if "-c" in flags else "0"
     bw = flags[flags.index("-w") + 1] if "-w" in flags else "150"
-    o = subprocess.run([ORC_RUN, prefix, str(b_dir / reads_name), mode[1], doc, rep, bw, "n", prefix + ".rawtext"],
-                       capture_output=True)
+    o = subprocess.run([ORC_RUN, prefix, str(b_dir / reads_name), mode[1], doc, rep, bw, digest, prefix + ".rawtext"]
+                       + orc_kw, capture_output=True)
     assert o.returncode == 0, o.stderr.decode()
     exts = [".pseudo_lengths"] if mode == "-P" else [".lengths", ".pointers"]
     if doc == "1":
@@ -247,3 +251,84 @@ def test_cli_empty_read_is_fatal_after_earlier_reads_were_written(built, tmp_pat
     for e in (".pseudo_lengths", ".report"):
         a, b = str(tmp_path / "gpu" / "reads.fa") + e, str(tmp_path / "orc" / "reads.fa") + e
         assert os.path.getsize(b) > 0 and filecmp.cmp(a, b, shallow=False), e
+
+
+def _setup_digested(tmp_path, oracle_mod, kind, k, w, seed):
+    """Raw index files over the digestion of a repetitive genome (prefix <ref>.bin for -m, <ref>.fa
+    for -a, src/spumoni.cpp:744-747) + DNA reads, some with N runs."""
+    from tests.sdsl_files import write_doc_array, write_null_db
+
+    rng = np.random.default_rng(seed)
+    genome = cases.repetitive_text(rng, 40000, list(b"ACGT"))
+    dtext = oracle_mod.digest(kind, k, w, genome)
+    raw = synth.index_from_text(torch.from_numpy(dtext.copy()), doc_lengths=[dtext.size // 3, dtext.size - dtext.size // 3])
+    ref = str(tmp_path / "ref")
+    prefix = ref + (".bin" if kind == 1 else ".fa")
+    open(prefix, "w").write(">dummy\n")
+    raw.write_raw_files(prefix)
+    dtext.tofile(prefix + ".rawtext")
+    write_doc_array(prefix + ".doc", raw.doc_start.numpy(), raw.doc_end.numpy())
+    write_null_db(prefix + ".pmlnulldb", 4.0, [1, 2, 3, 4, 4, 4, 4, 4])
+    write_null_db(prefix + ".msnulldb", 9.0, [5, 9, 9, 9, 9, 9])
+    seqs, offs = cases.reads_mixed(rng, genome, list(b"ACGT"), 300, 500, [ord("N")])
+    # every read must survive digestion here (the fatal case has its own test): drop short ones
+    keep = [q for q in range(offs.size - 1) if len(oracle_mod.digest(kind, k, w, seqs[offs[q]:offs[q + 1]])) > 0]
+    reads = [seqs[offs[q]:offs[q + 1]] for q in keep]
+    offs2 = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+    return ref, prefix, np.concatenate(reads), offs2, rng
+
+
+@pytest.mark.parametrize("digest,kw", [("m", ()), ("a", ()), ("m", (3, 9)), ("a", (2, 2))])
+def test_cli_with_minimizer_digestion(built, tmp_path, oracle_mod, digest, kw):
+    """`run -m` / `run -a`: reads are digested (on the device) before the walk, outputs are per
+    digested character (compute_ms_pml.cpp:919-938) -- byte-identical to the oracle harness."""
+    kind = 1 if digest == "m" else 2
+    k, w = kw if kw else (4, 11)
+    ref, prefix, seqs, offs, rng = _setup_digested(tmp_path, oracle_mod, kind, k, w, seed=60 + kind)
+    assert offs.size > 100
+    for mode, flags in (("-P", ["-c", "-d", "-w", "50"]), ("-M", ["-c", "-d", "-w", "50"]), ("-P", [])):
+        r = _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, flags, mode, digest=digest, kw=kw)
+        assert (b"promoted minimizer alphabet" if digest == "m" else b"DNA minimizer alphabet") in r.stderr
+
+
+def test_cli_read_empty_after_digestion_is_fatal_in_order(built, tmp_path, oracle_mod):
+    """:926-931 -- a read that digests to nothing (all N / shorter than one window) stops the run
+    at that read; what came before is on disk."""
+    ref, prefix, seqs, offs, rng = _setup_digested(tmp_path, oracle_mod, 1, 4, 11, seed=71)
+    for d in ("gpu", "orc"):
+        (tmp_path / d).mkdir(exist_ok=True)
+        with open(tmp_path / d / "reads.fa", "w") as f:
+            for q in range(25):
+                f.write(f">r{q}\n{seqs[offs[q]:offs[q + 1]].tobytes().decode()}\n")
+            f.write(">mostly_n\n" + "N" * 90 + "ACGTACGTAC\n>after\n" + "ACGTTGCA" * 10 + "\n")
+    r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(tmp_path / "gpu" / "reads.fa"), "-m", "-P", "-c"],
+                       capture_output=True)
+    o = subprocess.run([ORC_RUN, prefix, str(tmp_path / "orc" / "reads.fa"), "P", "0", "1", "150", "m"], capture_output=True)
+    assert r.returncode == 1 and o.returncode == 1
+    assert b"mostly_n was empty after digestion" in r.stderr and b"mostly_n was empty after digestion" in o.stderr
+    assert r.stdout.endswith(b"\n\n")
+    for e in (".pseudo_lengths", ".report"):
+        a, b = str(tmp_path / "gpu" / "reads.fa") + e, str(tmp_path / "orc" / "reads.fa") + e
+        assert os.path.getsize(b) > 0 and filecmp.cmp(a, b, shallow=False), e
+
+
+def test_end_to_end_minimizer_index_from_fasta(built, tmp_path):
+    """FASTA -> build_index -m (digestion on the device) -> run -m: positives FOUND, nulls not."""
+    g1 = synth.random_genome(60_000, seed=31)
+    g2 = synth.mutate(g1, seed=32)
+    for name, g in (("a.fa", g1), ("b.fa", g2)):
+        with open(tmp_path / name, "w") as f:
+            f.write(f">{name}\n{g.tobytes().decode()}\n")
+    (tmp_path / "list.txt").write_text(f"{tmp_path / 'a.fa'} 1\n{tmp_path / 'b.fa'} 2\n")
+    ref = str(tmp_path / "idx" / "pan")
+    r = subprocess.run(["python", "-m", "spumoni_amd.build_index", "-l", str(tmp_path / "list.txt"), "-o", ref, "--doc", "-m"],
+                       capture_output=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()
+    prefix = ref + ".bin"
+    dna = np.concatenate([g1, synth.revcomp(g1), g2, synth.revcomp(g2)])
+    seqs, offs = synth.sample_reads(dna, 400, 250, seed=5)
+    rng = np.random.default_rng(1)
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P", digest="m")
+    rep = open(tmp_path / "gpu" / "reads.fa.report").read().splitlines()[1:]
+    found = sum("FOUND" in ln and "NOT_PRESENT" not in ln for ln in rep)
+    assert 0.3 * len(rep) < found < 0.7 * len(rep)
