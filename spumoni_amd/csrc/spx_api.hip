@@ -305,6 +305,10 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->force_lanes_per_wave = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "digest_kernel")) {
+        ix->force_digest_kernel = (int)value;
+        return SPX_OK;
+    }
     if (!strcmp(key, "minimizer_charhash")) {
         for (int c = 0; c < 4; ++c) ix->charhash[c] = (uint8_t)((uint64_t)value >> (8 * c));
         return SPX_OK;
@@ -335,7 +339,7 @@ int spx_digest_batch_device(spx_index* ix, int kind, uint32_t k, uint32_t w, con
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
-    return launch_digest(ix, kind, k, w, d_seqs, d_offsets, nreads, d_out_seqs, d_out_offsets, st);
+    return launch_digest(ix, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_out_seqs, d_out_offsets, st);
 }
 
 // grow-only device scratch owned by the index (no hipMalloc/hipFree per call); callers hold host_mu

@@ -50,7 +50,7 @@ __device__ __forceinline__ int base_code(uint32_t c) {
 }
 
 template <int PASS>
-__global__ void __launch_bounds__(64) k_digest(const DigestArgs a) {
+__global__ void __launch_bounds__(64) k_digest_wave(const DigestArgs a) {
     extern __shared__ uint8_t lds[];
     uint8_t* const keys = lds;            // ring of stream keys
     uint8_t* const mins = lds + a.ring;   // ring of window minima, by stream index
@@ -117,6 +117,144 @@ __global__ void __launch_bounds__(64) k_digest(const DigestArgs a) {
     }
 }
 
+
+// ---- lane-per-read variant: short reads, windows of at most 8 k-mers ------------------------
+// 64 consecutive reads are one contiguous stretch of `seqs`: the wavefront copies it into LDS
+// with coalesced 16-byte loads (TILE bytes at a time) and every lane then walks ITS read
+// sequentially, exactly like the reference's loop -- k-mer in a register, the window's keys in
+// one 64-bit register (newest in the low byte), minimum by packed 16-bit mins.  No ballots, no
+// stream compaction: a character outside ACGT just resets the lane's k-mer fill.
+constexpr uint32_t TILE = 16384;
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y) {
+    us2 a = __builtin_bit_cast(us2, x), b = __builtin_bit_cast(us2, y);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(a, b));
+}
+
+// least byte of a 64-bit word
+__device__ __forceinline__ uint32_t byte_min8(uint64_t w) {
+    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    const uint32_t m = pk_min_u16(pk_min_u16(lo & 0x00ff00ffu, (lo >> 8) & 0x00ff00ffu),
+                                  pk_min_u16(hi & 0x00ff00ffu, (hi >> 8) & 0x00ff00ffu));
+    return min(m & 0xffffu, m >> 16);
+}
+
+template <int PASS, int KIND>
+__global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
+    __shared__ uint4 tile16[TILE / 16 + 1];  // + slack for the last 4-byte read of a read
+    __shared__ uint8_t lut[256];
+    const uint8_t* const tile = reinterpret_cast<const uint8_t*>(tile16);
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) lut[i] = a.key_of_kmer[i];
+    const uint32_t k = a.k, wsz = a.wsz;
+    const uint32_t kmask = (1u << (2 * k)) - 1;
+    const uint64_t hm = wsz >= 8 ? 0ull : (~0ull << (8 * wsz));  // window bytes that do not exist
+    const uint64_t ngroups = (a.nreads + 63) / 64;
+    for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint64_t rd = grp * 64 + lane;
+        const bool live = rd < a.nreads;
+        const uint64_t rbeg = a.offs[live ? rd : a.nreads];
+        const uint64_t rend = a.offs[live ? rd + 1 : a.nreads];
+        const uint64_t g0 = __shfl(rbeg, 0), g1 = __shfl(rend, 63);
+        uint64_t ob = 0;
+        if (PASS == 1 && live) ob = a.out_offs[rd];
+        // the lane's walk state
+        uint32_t filled = 0, kmer = 0, cnt = 0, last = 0, acc = 0, nacc = 0;
+        bool have = false;
+        uint64_t win = 0, e = 0;
+        auto push_byte = [&](uint32_t v) {  // PASS 1: byte e of this read's digest
+            const uint64_t addr = ob + e;
+            acc |= v << (8 * (uint32_t)(addr & 3));
+            nacc++;
+            e++;
+            if (((addr + 1) & 3) == 0) {  // the aligned dword that holds addr is complete
+                if (nacc == 4) {
+                    *reinterpret_cast<uint32_t*>(a.out + (addr - 3)) = acc;
+                } else {  // its first bytes belong to the previous read
+                    for (uint32_t j = 4 - nacc; j < 4; ++j) a.out[addr - 3 + j] = (uint8_t)(acc >> (8 * j));
+                }
+                acc = 0;
+                nacc = 0;
+            }
+        };
+        for (uint64_t t0 = g0 & ~15ull; t0 < g1; t0 += TILE) {
+            __syncthreads();  // everybody is done with the previous tile (and the LUT is in place)
+            const uint64_t tend = min(t0 + TILE, (g1 + 15) & ~15ull);
+            {  // all loads of the tile in flight before the first LDS write; slots past the
+               // end of the stretch re-read its first chunk (always a valid address) and are never used
+                uint4 v[TILE / 16 / 64];
+#pragma unroll
+                for (uint32_t j = 0; j < TILE / 16 / 64; ++j) {
+                    const uint64_t g = t0 + ((uint64_t)j * 64 + lane) * 16;
+                    v[j] = *reinterpret_cast<const uint4*>(a.seqs + (g < tend ? g : t0));
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < TILE / 16 / 64; ++j) tile16[j * 64 + lane] = v[j];
+            }
+            __syncthreads();
+            const uint64_t lo = max(rbeg, t0), hi = min(rend, t0 + TILE);
+            const uint32_t mine = hi > lo ? (uint32_t)(hi - lo) : 0;
+            const uint32_t off = (uint32_t)(lo - t0);  // only used when mine > 0
+            uint32_t longest = mine;
+            for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, s));
+            for (uint32_t s = 0; s < longest; s += 4) {
+                // four characters of this lane's read (bytes past `mine` are ignored below; the
+                // tile array is over-allocated so that the read stays inside LDS)
+                uint32_t w4 = 0;
+                if (s < mine) __builtin_memcpy(&w4, tile + off + s, 4);
+                uint32_t kmers[4], keys[4];
+                bool act[4], has[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t ch = (w4 >> (8 * j)) & 0xffu;
+                    act[j] = s + j < mine;
+                    const uint32_t d = ch - 'A';
+                    const bool valid = d < 20 && ((0x80045u >> d) & 1);  // A C G T
+                    const uint32_t nf = valid ? min(filled + 1, k) : 0;
+                    filled = act[j] ? nf : filled;
+                    const uint32_t nk = ((kmer << 2) | (((ch >> 1) ^ (ch >> 2)) & 3)) & kmask;  // A0 C1 G2 T3
+                    kmer = act[j] ? nk : kmer;
+                    kmers[j] = kmer;
+                    has[j] = act[j] && filled == k;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    keys[j] = KIND == SPX_DIGEST_PROMOTED ? (uint32_t)lut[kmers[j]] : (kmers[j] ^ a.xm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    win = has[j] ? ((win << 8) | keys[j]) : win;
+                    cnt = has[j] ? min(cnt + 1, wsz) : cnt;
+                    const uint32_t mn = byte_min8(win | hm);
+                    const bool em = has[j] && cnt == wsz && (!have || mn != last);
+                    last = em ? mn : last;
+                    have = have || em;
+                    if (PASS == 0) {
+                        e += em ? 1 : 0;
+                    } else if (em) {
+                        if (KIND == SPX_DIGEST_PROMOTED) {
+                            push_byte(mn > 2 ? mn : mn + 3);
+                        } else {
+                            const uint32_t code_min = mn ^ a.xm;
+                            for (uint32_t t = 0; t < k; ++t)
+                                push_byte((uint32_t)"ACGT"[(code_min >> (2 * (k - 1 - t))) & 3]);
+                        }
+                    }
+                }
+            }
+        }
+        if (PASS == 1) {
+            for (uint32_t j = 0; j < nacc; ++j) {
+                const uint64_t addr = ob + e - nacc + j;
+                a.out[addr] = (uint8_t)(acc >> (8 * (uint32_t)(addr & 3)));
+            }
+        } else if (live) {
+            a.counts[rd + 1] = e * (KIND == SPX_DIGEST_DNA ? k : 1);
+        }
+    }
+}
+
 // the walk reads its characters in aligned 32-byte windows past the last read: define the tail
 __global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* out) {
     const uint64_t total = out_offs[nreads];
@@ -127,7 +265,7 @@ __global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* 
 }  // namespace
 
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
-                  uint64_t nreads, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st) {
+                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st) {
     if (kind != SPX_DIGEST_PROMOTED && kind != SPX_DIGEST_DNA) {
         set_error("digest kind must be SPX_DIGEST_PROMOTED (-m) or SPX_DIGEST_DNA (-a)");
         return SPX_E_ARG;
@@ -176,10 +314,32 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, 0, d_out);
         return SPX_OK;
     }
-    const size_t lds = 2 * (size_t)ring + 256;
-    const uint64_t max_blocks = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256) * 64;
-    const uint32_t grid = (uint32_t)(nreads < max_blocks ? nreads : max_blocks);
-    k_digest<0><<<grid, 64, lds, st>>>(a);
+    // short reads and a window that fits a register: one lane per read; otherwise one
+    // wavefront per read (any length, any window)
+    const uint64_t mean_len = total_chars / nreads;
+    bool lanes = a.wsz <= 8 && mean_len <= 2048;
+    if (ix->force_digest_kernel == 1) lanes = a.wsz <= 8;
+    if (ix->force_digest_kernel == 2) lanes = false;
+    const uint64_t cus = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256);
+    auto pass = [&](int which) {
+        if (lanes) {
+            const uint64_t groups = (nreads + 63) / 64;
+            const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
+            if (kind == SPX_DIGEST_PROMOTED) {
+                if (which == 0) k_digest_lanes<0, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
+                else k_digest_lanes<1, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
+            } else {
+                if (which == 0) k_digest_lanes<0, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
+                else k_digest_lanes<1, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
+            }
+        } else {
+            const size_t lds = 2 * (size_t)ring + 256;
+            const uint32_t grid = (uint32_t)(nreads < cus * 64 ? nreads : cus * 64);
+            if (which == 0) k_digest_wave<0><<<grid, 64, lds, st>>>(a);
+            else k_digest_wave<1><<<grid, 64, lds, st>>>(a);
+        }
+    };
+    pass(0);
     SPX_HIP(hipGetLastError());
     // counts -> offsets, in place
     size_t tmp_bytes = 0;
@@ -188,7 +348,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
     SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
     SPX_HIP(hipFreeAsync(tmp, st));
-    k_digest<1><<<grid, 64, lds, st>>>(a);
+    pass(1);
     k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
     SPX_HIP(hipGetLastError());
     return SPX_OK;

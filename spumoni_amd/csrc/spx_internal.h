@@ -76,6 +76,7 @@ struct spx_index {
     int occ_blocks[4] = {0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant
     int num_cus = 0;
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
+    int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read
     uint8_t charhash[4] = {0, 0, 0, 0};  // -m digestion: 8-bit character hashes of A, C, G, T
     std::mutex mu;       // device-buffer queries / options
     std::mutex host_mu;  // host-buffer queries (own the scratch below)
@@ -98,5 +99,5 @@ int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // spx_digest.hip: d_out_offs gets nreads + 1 offsets, d_out the digested reads (capacity is the
 // caller's business: spx_digest_capacity)
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
-                  uint64_t nreads, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t stream);
+                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t stream);
 }  // namespace spx

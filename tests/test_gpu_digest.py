@@ -40,12 +40,15 @@ def _ragged_dna(rng, nreads, maxlen, p_n):
 def test_digest_matches_oracle(gpu, oracle_mod, small_index, kind, k, w):
     ix = small_index[2]
     rng = np.random.default_rng(100 * k + w + kind)
-    for p_n in (0.0, 0.05):
-        seqs, offs = _ragged_dna(rng, 400, 700, p_n)
+    for p_n, maxlen in ((0.0, 700), (0.05, 700), (0.01, 120)):
+        seqs, offs = _ragged_dna(rng, 400, maxlen, p_n)
         want, want_offs = oracle_mod.digest_batch(kind, k, w, seqs, offs)
-        got, got_offs = ix.digest_host(kind, k, w, seqs, offs)
-        assert np.array_equal(got_offs, want_offs)
-        assert np.array_equal(got, want)
+        for forced in (0, 1, 2):  # automatic, lane-per-read (when the window allows), wavefront-per-read
+            ix.set_option("digest_kernel", forced)
+            got, got_offs = ix.digest_host(kind, k, w, seqs, offs)
+            assert np.array_equal(got_offs, want_offs), forced
+            assert np.array_equal(got, want), forced
+    ix.set_option("digest_kernel", 0)
 
 
 def test_digest_edge_batches(gpu, oracle_mod, small_index):
@@ -62,8 +65,10 @@ def test_digest_edge_batches(gpu, oracle_mod, small_index):
             offs = np.array([0, seqs.size], np.uint64)
         for kind in (1, 2):
             want, want_offs = oracle_mod.digest_batch(kind, 4, 11, seqs, offs)
-            got, got_offs = ix.digest_host(kind, 4, 11, seqs, offs)
-            assert np.array_equal(got_offs, want_offs) and np.array_equal(got, want)
+            for forced in (1, 2, 0):
+                ix.set_option("digest_kernel", forced)
+                got, got_offs = ix.digest_host(kind, 4, 11, seqs, offs)
+                assert np.array_equal(got_offs, want_offs) and np.array_equal(got, want)
     # lower-case and IUPAC letters are not ACGT: the caller upper-cases (compute_ms_pml.cpp:916-917)
     seqs = np.frombuffer(b"acgtacgtacgtacgtRYKMACGTACGTACGTACG", np.uint8)
     offs = np.array([0, seqs.size], np.uint64)
