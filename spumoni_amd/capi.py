@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspumoni_gpu.so")
+# SPUMONI_GPU_LIB: load another build of the same library (A/B experiments: tools/ab.sh)
+LIB_PATH = os.environ.get("SPUMONI_GPU_LIB") or os.path.join(_HERE, "libspumoni_gpu.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SPX_MODE_PML = 0

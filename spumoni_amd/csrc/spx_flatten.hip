@@ -121,7 +121,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
                              const uint64_t* S, const uint64_t* lens, const uint32_t* nzpos,
                              const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
                              const uint64_t* de, const LetterInfo* letters, const uint8_t* Hrun,
-                             uint64_t r, uint64_t n, Row* rows, JumpRow* dirrows, uint32_t* dirdocs,
+                             uint64_t r, uint64_t n, int compact, Row* rows, JumpRow* dirrows, uint32_t* dirdocs,
                              uint32_t* rundocs, unsigned long long* err) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
@@ -155,7 +155,18 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
         trun = thr >= n ? r : upper_bound_u64(S, r, thr) - 1;
         toff = thr - S[trun];
     }
-    rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
+    if (compact) {
+        uint32_t cum[4];
+        uint64_t acc = S[dst + 1] - S[dst] - soff;
+        for (int t = 0; t < 4; ++t) {
+            cum[t] = acc < CUM_SAT ? (uint32_t)acc : CUM_SAT;
+            const uint64_t nx = dst + 1 + t;
+            acc = (acc >= CUM_SAT || nx >= r) ? CUM_SAT : acc + (S[nx + 1] - S[nx]);
+        }
+        rows[k] = pack_row_compact(c, (uint32_t)lens[k], (uint32_t)dst, (uint32_t)soff, thr <= S[k], cum);
+    } else {
+        rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
+    }
     // predecessor landing = LF(S[k]) - 1 = LF of the last character of the previous run in
     // directory order
     const bool psame = soff > 0;  // for i == 0 (lf == 0) there is no predecessor: never taken
@@ -177,9 +188,22 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
     }
 }
 
-__global__ void k_sentinel_rows(Row* rows, uint64_t r) {
+__global__ void k_sentinel_rows(Row* rows, uint64_t r, int compact) {
     int t = threadIdx.x;
-    if (t < ROW_PAD) rows[r + t] = pack_row(0, MASK40, (uint32_t)r, 0, true, ROOM_SAT);
+    const uint32_t sat[4] = {CUM_SAT, CUM_SAT, CUM_SAT, CUM_SAT};
+    if (t < ROW_PAD)
+        rows[r + t] = compact ? pack_row_compact(0, 0xffff, (uint32_t)r, 0, true, sat)
+                              : pack_row(0, MASK40, (uint32_t)r, 0, true, ROOM_SAT);
+}
+
+__global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* out) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    unsigned long long v = i < r ? lens[i] : 0;
+    for (int s = 32; s > 0; s >>= 1) {
+        const unsigned long long o = __shfl_xor(v, s);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
 
 // block count table: cnt[lid][b] = directory offset of the first c-run with index >= b << s
@@ -340,12 +364,22 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(hipMalloc((void**)&ix->dirdocs, (r + ROW_PAD) * 4));
         SPX_HIP(hipMalloc((void**)&ix->rundocs, (r + ROW_PAD) * 4));
     }
+    unsigned long long max_len = 0;
+    {
+        DevBuf ml;
+        SPX_HIP(ml.alloc(8));
+        SPX_HIP(hipMemsetAsync(ml.p, 0, 8, st));
+        k_max_len<<<nblocks(r), TPB, 0, st>>>(d_lens, r, ml.as<unsigned long long>());
+        SPX_HIP(hipMemcpyAsync(&max_len, ml.p, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
+    }
+    const int compact = (max_len < 65536 && !getenv("SPX_ROWS_WIDE")) ? 1 : 0;
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters,
-                                              H.as<uint8_t>(), r, n, ix->rows, ix->dirrows, ix->dirdocs,
+                                              H.as<uint8_t>(), r, n, compact, ix->rows, ix->dirrows, ix->dirdocs,
                                               ix->rundocs, err.as<unsigned long long>());
-    k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r);
+    k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, compact);
     SPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(T.p);
     T.p = nullptr;
@@ -448,6 +482,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.n_text = 0;
     v.n = n;
     v.r = (uint32_t)r;
+    v.compact = (uint32_t)compact;
     v.nblk = nblk;
     v.bshift = bshift;
     v.init_k = (uint32_t)(r - 1);

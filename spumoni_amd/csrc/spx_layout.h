@@ -72,6 +72,32 @@ SPX_HD uint32_t row_LFrun(const Row& r) {
 SPX_HD uint64_t row_LFoff(const Row& r) { return r.q1 & MASK40; }
 SPX_HD bool row_thr_ok(const Row& r) { return (r.q1 >> 56) & 1; }
 
+// Compact encoding of the same 16 bytes, used for the whole index when every run is shorter
+// than 2^16 (DevIndex::compact):
+//     q0: len[16] | LFoff[16] << 16 | LFrun[32] << 32
+//     q1: H[8] | thr_ok << 8 | cum0..cum3 [7 bits in a byte each] << 32
+// cum_i = (len[LFrun] - LFoff) + len[LFrun+1] + ... + len[LFrun+i], saturated at 127: the
+// offsets at which a match step leaves run LFrun, LFrun+1, ...  A step with offset `off` lands
+// in run LFrun + t at offset off - cum_{t-1}, t = #{i : cum_i <= off} -- known BEFORE the
+// gather, so the walk fetches the row it really lands in instead of walking the chain
+// LFrun, LFrun+1, ... one gather at a time (0.27 gathers per character on the bench index).
+constexpr uint32_t CUM_SAT = 127;
+SPX_HD Row pack_row_compact(uint32_t H, uint32_t len, uint32_t LFrun, uint32_t LFoff, bool thr_ok,
+                            const uint32_t cum[4]) {
+    Row r;
+    r.q0 = (uint64_t)(len & 0xffff) | ((uint64_t)(LFoff & 0xffff) << 16) | ((uint64_t)LFrun << 32);
+    uint64_t c = 0;
+    for (int i = 0; i < 4; ++i) c |= (uint64_t)(cum[i] < CUM_SAT ? cum[i] : CUM_SAT) << (8 * i);
+    r.q1 = (uint64_t)(H & 0xff) | ((uint64_t)(thr_ok ? 1 : 0) << 8) | (c << 32);
+    return r;
+}
+SPX_HD uint32_t crow_len(const Row& r) { return (uint32_t)r.q0 & 0xffff; }
+SPX_HD uint32_t crow_LFoff(const Row& r) { return ((uint32_t)r.q0 >> 16) & 0xffff; }
+SPX_HD uint32_t crow_LFrun(const Row& r) { return (uint32_t)(r.q0 >> 32); }
+SPX_HD uint32_t crow_H(const Row& r) { return (uint32_t)r.q1 & 0xff; }
+SPX_HD bool crow_thr_ok(const Row& r) { return (r.q1 >> 8) & 1; }
+SPX_HD uint32_t crow_cums(const Row& r) { return (uint32_t)(r.q1 >> 32); }
+
 struct alignas(32) JumpRow {
     uint64_t d0;  // q[32] | THRrun[32] << 32
     uint64_t d1;  // THRoff[40] | sLFrun[0:24] << 40
@@ -141,6 +167,7 @@ struct DevIndex {
     uint64_t n_text;
     uint64_t n;
     uint32_t r;
+    uint32_t compact;   // rows use the compact encoding (every run shorter than 2^16)
     uint32_t nblk;      // blocks per letter in fat (= (r >> bshift) + 2)
     uint32_t bshift;    // log2(runs per directory block)
     uint32_t init_k;    // run of position n-1  (= r-1)

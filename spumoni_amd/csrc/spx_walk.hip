@@ -64,6 +64,20 @@ __device__ __forceinline__ void lf_target(uint32_t LFrun, uint64_t LFoff, uint32
     offp = over ? off - room : LFoff + off;
 }
 
+// The same for compact rows (spx_layout.h): cums = the offsets at which the step leaves runs
+// LFrun, LFrun+1, LFrun+2, LFrun+3 (saturated at 127), so the destination run is known exactly
+// unless it lies further than that.
+__device__ __forceinline__ void lf_target_c(uint32_t LFrun, uint64_t LFoff, uint32_t cums, uint64_t off,
+                                            uint32_t& k0, uint64_t& offp) {
+    const uint32_t o = off < 126 ? (uint32_t)off : 126u;
+    // byte i gets its top bit iff cum_i <= o (no borrows: every byte of the minuend is >= 128)
+    const uint32_t flags = (((o * 0x01010101u) | 0x80808080u) - cums) & 0x80808080u;
+    const uint32_t t = __popc(flags);  // cums ascend: the bytes that qualify are a prefix
+    const uint32_t prev = (cums >> (8 * ((t + 3) & 3))) & 0x7fu;  // cum_{t-1} (unused when t == 0)
+    k0 = LFrun + t;
+    offp = t ? off - prev : LFoff + off;
+}
+
 // Output staging: values < 65536 of the aligned group of 8 outputs [g8, g8+8) are collected
 // as u16 in two registers while the walk descends and written as two 16-byte stores when
 // the group is complete (one full 32-byte sector); groups cut by the read's ends fall back
@@ -105,7 +119,7 @@ __device__ __forceinline__ void stage8(uint64_t& lo, uint64_t& hi, uint32_t valu
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
 // ---------------------------------------------------------------------------
-template <int MODE, bool DOC>
+template <int MODE, bool DOC, bool COMPACT>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
     constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
     __shared__ LetterInfo s_let[256];
@@ -153,6 +167,13 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t n_steps = 0, n_jumps = 0, n_pred = 0, n_rows = 0, n_dir = 0, n_err = 0;
 
     if (rd >= b.nreads || (threadIdx.x & 63) >= lpw) ph = P_DONE;
+#define LF_TARGET()                                                      \
+    do {                                                                 \
+        if (COMPACT)                                                     \
+            lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp);        \
+        else                                                             \
+            lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);          \
+    } while (0)
 
     while (ph != P_DONE) {
         // ---- the one gather of this iteration -------------------------------
@@ -208,7 +229,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             Row ra;
             ra.q0 = g0;
             ra.q1 = g1;
-            const uint64_t len = row_len(ra);
+            const uint64_t len = COMPACT ? (uint64_t)crow_len(ra) : row_len(ra);
             if (offp == OFF_END) offp = len - 1;  // predecessor landing: last position of this run
             if (offp >= len) {  // LF image lies in a later run: skip this row
                 offp -= len;
@@ -216,11 +237,19 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else {
                 k = k0;
                 off = offp;
-                H_k = row_H(ra);
-                LFrun_k = row_LFrun(ra);
-                LFoff_k = row_LFoff(ra);
-                thr_ok_k = row_thr_ok(ra);
-                room_k = row_room(ra);
+                if (COMPACT) {
+                    H_k = crow_H(ra);
+                    LFrun_k = crow_LFrun(ra);
+                    LFoff_k = crow_LFoff(ra);
+                    thr_ok_k = crow_thr_ok(ra);
+                    room_k = crow_cums(ra);
+                } else {
+                    H_k = row_H(ra);
+                    LFrun_k = row_LFrun(ra);
+                    LFoff_k = row_LFoff(ra);
+                    thr_ok_k = row_thr_ok(ra);
+                    room_k = row_room(ra);
+                }
                 do_step = true;
             }
         } else if (ph == P_FAT) {
@@ -298,7 +327,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1): stays there
             if (MODE == SPX_MODE_MS) sample = g0;  // samples_start[run of pos]
             if (DOC) doc = dd & 0xffff;            // start_runs_doc[run of pos]
-            lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
+            LF_TARGET();
             do_emit = true;
         }
 
@@ -388,7 +417,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
                     length++;
                     sample--;  // :582 (wraps, Appendix C3)
-                    lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
+                    LF_TARGET();
                     do_emit = true;
                 } else if (k < R && H_k == c && thr_ok_k) {
                     // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
@@ -399,7 +428,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     if (AUX) {
                         ph = P_SAMP;  // sample = samples_start[k], doc = start_runs_doc[k]
                     } else {
-                        lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);
+                        LF_TARGET();
                         do_emit = true;
                     }
                 } else {
@@ -502,6 +531,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             }
             peek = false;
         }
+        // One flat loop, one back edge.  Hiding the phase from the optimiser here keeps it from
+        // threading the "read finished" path into a back edge of its own and splitting the loop
+        // into an outer per-read and an inner per-character loop -- in which every lane waits at
+        // the end of its read for the slowest lane of the wavefront (seen once: 19.3 ms vs 11 ms).
+        asm volatile("" : "+v"(ph));
     }
 
     atomicAdd(&b.counters->steps, (unsigned long long)n_steps);
@@ -638,13 +672,13 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     }
 }
 
-template <int MODE, bool DOC>
+template <int MODE, bool DOC, bool COMPACT>
 int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
-        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC>, WALK_TPB, 0));
+        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
     }
     if (ix->num_cus == 0) {
@@ -687,7 +721,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
         grid = (args.nreads + lpw - 1) / lpw;
     }
     if (grid == 0) grid = 1;
-    k_walk_lanes<MODE, DOC><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+    k_walk_lanes<MODE, DOC, COMPACT><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
@@ -698,10 +732,16 @@ int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_c
                 hipStream_t stream) {
     (void)total_chars;
     const bool doc = args.out_docs != nullptr;
-    if (mode == SPX_MODE_PML) return doc ? launch_lanes<SPX_MODE_PML, true>(ix, args, stream)
-                                          : launch_lanes<SPX_MODE_PML, false>(ix, args, stream);
-    return doc ? launch_lanes<SPX_MODE_MS, true>(ix, args, stream)
-               : launch_lanes<SPX_MODE_MS, false>(ix, args, stream);
+    if (ix->view.compact) {
+        if (mode == SPX_MODE_PML) return doc ? launch_lanes<SPX_MODE_PML, true, true>(ix, args, stream)
+                                              : launch_lanes<SPX_MODE_PML, false, true>(ix, args, stream);
+        return doc ? launch_lanes<SPX_MODE_MS, true, true>(ix, args, stream)
+                   : launch_lanes<SPX_MODE_MS, false, true>(ix, args, stream);
+    }
+    if (mode == SPX_MODE_PML) return doc ? launch_lanes<SPX_MODE_PML, true, false>(ix, args, stream)
+                                          : launch_lanes<SPX_MODE_PML, false, false>(ix, args, stream);
+    return doc ? launch_lanes<SPX_MODE_MS, true, false>(ix, args, stream)
+               : launch_lanes<SPX_MODE_MS, false, false>(ix, args, stream);
 }
 
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream) {

@@ -267,6 +267,21 @@ def statistical_rlbwt(
     lens[0] = 1
     if r > 1 and int(heads[1]) == 0:
         heads[1] = int(lt[0])
+    return raw_from_runs(heads, lens, g, with_samples, n_docs)
+
+
+def raw_from_runs(heads: torch.Tensor, lens: torch.Tensor, seed_or_gen, with_samples: bool = False,
+                  n_docs: int = 0) -> RawIndex:
+    """RawIndex over given run heads (u8, no equal neighbours, exactly one terminator run with head
+    0) and run lengths: thresholds uniform in (end of previous same-letter run, start of this run],
+    random SA samples / document ids."""
+    dev = heads.device
+    r = int(heads.numel())
+    if isinstance(seed_or_gen, torch.Generator):
+        g = seed_or_gen
+    else:
+        g = torch.Generator(device=dev)
+        g.manual_seed(int(seed_or_gen))
     ends_excl = torch.cumsum(lens, 0)
     starts = ends_excl - lens
     n = int(ends_excl[-1].item())

@@ -65,7 +65,10 @@ def _compare_all(oracle_mod, raw, text, seqs, offs, ix=None):
         (5, 64, [ord("A")], [ord("C")]),
     ],
 )
-def test_real_bwt_parity(gpu, oracle_mod, seed, n, letters, extra):
+@pytest.mark.parametrize("wide_rows", [0, 1])
+def test_real_bwt_parity(gpu, oracle_mod, seed, n, letters, extra, wide_rows, monkeypatch):
+    if wide_rows:  # the general row encoding (runs of 2^16 and more) on an index that would be compact
+        monkeypatch.setenv("SPX_ROWS_WIDE", "1")
     raw, text = cases.real_case(seed, n, letters)
     rng = np.random.default_rng(1000 + seed)
     seqs, offs = cases.reads_mixed(rng, text, letters, 300, 120, extra)
@@ -243,11 +246,14 @@ def test_limits_are_enforced(gpu):
         ix.query_host(capi.SPX_MODE_PML, rd, offs, want_docs=True)
 
 
-@pytest.mark.parametrize("bshift", [0, 2, 5, 9])
-def test_every_directory_block_size(gpu, oracle_mod, bshift, monkeypatch):
+@pytest.mark.parametrize("bshift,wide_rows", [(0, 0), (2, 1), (5, 0), (9, 1)])
+def test_every_directory_block_size(gpu, oracle_mod, bshift, wide_rows, monkeypatch):
     """The fat-table block size is chosen from the free memory; force it from 1 to 512 runs per
-    block so that the direct answer, the one-window and the multi-window directory scans all run."""
+    block so that the direct answer, the one-window and the multi-window directory scans all run
+    (with both row encodings)."""
     monkeypatch.setenv("SPX_FAT_BSHIFT", str(bshift))
+    if wide_rows:
+        monkeypatch.setenv("SPX_ROWS_WIDE", "1")
     for seed, letters in ((61, DNA), (62, [3, 4, 5, 90, 127, 128, 129, 200, 255])):
         raw, text = cases.real_case(seed, 6000, letters)
         rng = np.random.default_rng(seed)
@@ -256,3 +262,41 @@ def test_every_directory_block_size(gpu, oracle_mod, bshift, monkeypatch):
     raw = synth.statistical_rlbwt(30000, 16, 2.0, seed=7, device="cuda", with_samples=True, n_docs=5)
     seqs, offs = synth.simulate_reads(raw, 3000, 50, seed=8, positive_fraction=0.3)
     _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy())
+
+
+def test_long_runs_and_far_thresholds(gpu, oracle_mod):
+    """Runs of 2^16 and more (the index then keeps the general row encoding instead of the compact
+    one) and a letter whose two runs -- and so a threshold and its run -- lie 1.5 * 2^20 runs apart."""
+    rng = np.random.default_rng(5)
+    acg = np.frombuffer(b"ACG", dtype=np.uint8)
+    # (1) long runs among short ones
+    r = 4000
+    idx = rng.integers(0, 3, size=r)
+    for i in range(1, r):
+        if idx[i] == idx[i - 1]:
+            idx[i] = (idx[i] + 1) % 3
+    heads = acg[idx].copy()
+    lens = rng.integers(1, 6, size=r).astype(np.int64)
+    big = rng.random(r) < 0.05
+    lens[big] = rng.integers(1 << 16, 3 << 16, size=int(big.sum()))
+    heads[r // 2], lens[r // 2] = 0, 1
+    raw = synth.raw_from_runs(torch.from_numpy(heads), torch.from_numpy(lens), 3, with_samples=True, n_docs=4)
+    seqs, offs = synth.simulate_reads(raw, 2000, 60, seed=9, positive_fraction=0.5)
+    _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy())
+    # (2) a letter with two runs 1.5 * 2^20 runs apart
+    r = (1 << 21) + 1000
+    idx = rng.integers(0, 3, size=r)
+    eq = np.flatnonzero(idx[1:] == idx[:-1]) + 1
+    while eq.size:
+        idx[eq] = (idx[eq] + 1) % 3
+        eq = np.flatnonzero(idx[1:] == idx[:-1]) + 1
+    heads = acg[idx].copy()
+    lens = rng.integers(1, 4, size=r).astype(np.int64)
+    heads[0], lens[0] = 0, 1
+    heads[500] = heads[500 + (3 << 19)] = ord("T")
+    for seed in (1, 2, 3):  # the threshold is drawn uniformly between the two T runs
+        raw = synth.raw_from_runs(torch.from_numpy(heads), torch.from_numpy(lens), seed, with_samples=True, n_docs=3)
+        seqs, offs = synth.simulate_reads(raw, 20000, 40, seed=seed, positive_fraction=0.5)
+        seqs = seqs.cpu().numpy().copy()
+        seqs[rng.random(seqs.size) < 0.05] = ord("T")  # jumps to the rare letter from everywhere
+        _compare_all(oracle_mod, raw, None, seqs, offs.cpu().numpy())
