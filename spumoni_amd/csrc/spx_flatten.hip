@@ -487,6 +487,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.bshift = bshift;
     v.init_k = (uint32_t)(r - 1);
     v.init_off = last_len - 1;
+    SPX_HIP(hipMemcpy(&v.init_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost));
     v.init_sample = ix->samples ? (last_esa + 1) % n : 0;
     v.init_doc = (uint32_t)last_de;
     v.doc_at0 = (uint32_t)first_ds;

@@ -172,6 +172,7 @@ struct DevIndex {
     uint32_t bshift;    // log2(runs per directory block)
     uint32_t init_k;    // run of position n-1  (= r-1)
     uint64_t init_off;  // (n-1) - S[r-1]
+    Row init_row;       // rows[r-1]: every read starts on it, so the walk never gathers it
     uint64_t init_sample;  // get_last_run_sample(): (samples_last[r-1] + 1) % n
     uint32_t init_doc;     // end_runs_doc[r-1]         (compute_ms_pml.cpp:298)
     uint32_t doc_at0;      // start_runs_doc[run_of_position(0)]   (:641-642)

@@ -27,6 +27,8 @@
 // unique, all 64 lanes of a wave always have their gather in flight together
 // no matter which phase each is in: no lane waits for another lane's longer
 // step, and no phase serialises behind another phase's s_waitcnt.
+#include <type_traits>
+
 #include "spx_internal.h"
 
 namespace spx {
@@ -57,8 +59,9 @@ __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) {
 
 // LF of position (k, off) given row k's move pointer: the run LFrun at offset LFoff + off, or --
 // when the row's `room` says the offset overshoots that run -- the next run directly.
-__device__ __forceinline__ void lf_target(uint32_t LFrun, uint64_t LFoff, uint32_t room, uint64_t off,
-                                          uint32_t& k0, uint64_t& offp) {
+template <class OFFS>
+__device__ __forceinline__ void lf_target(uint32_t LFrun, OFFS LFoff, uint32_t room, OFFS off, uint32_t& k0,
+                                          OFFS& offp) {
     const bool over = room < ROOM_SAT && off >= room;
     k0 = LFrun + (over ? 1u : 0u);
     offp = over ? off - room : LFoff + off;
@@ -67,8 +70,9 @@ __device__ __forceinline__ void lf_target(uint32_t LFrun, uint64_t LFoff, uint32
 // The same for compact rows (spx_layout.h): cums = the offsets at which the step leaves runs
 // LFrun, LFrun+1, LFrun+2, LFrun+3 (saturated at 127), so the destination run is known exactly
 // unless it lies further than that.
-__device__ __forceinline__ void lf_target_c(uint32_t LFrun, uint64_t LFoff, uint32_t cums, uint64_t off,
-                                            uint32_t& k0, uint64_t& offp) {
+template <class OFFS>
+__device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t cums, OFFS off, uint32_t& k0,
+                                            OFFS& offp) {
     const uint32_t o = off < 126 ? (uint32_t)off : 126u;
     // byte i gets its top bit iff cum_i <= o (no borrows: every byte of the minuend is >= 128)
     const uint32_t flags = (((o * 0x01010101u) | 0x80808080u) - cums) & 0x80808080u;
@@ -144,11 +148,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t m = 0, x = 0;  // x = characters still to search; next one is index x-1
     // landed position: run k, offset off; fields of row k
     uint32_t k = 0, H_k = 0, LFrun_k = 0, room_k = 0;
-    uint64_t off = 0, LFoff_k = 0;
+    // offsets inside runs: 16 bits are enough with compact rows, 40 bits otherwise
+    typedef typename std::conditional<COMPACT, uint32_t, uint64_t>::type offs_t;
+    constexpr offs_t OFF_LAST = (offs_t)OFF_END;  // "last position of the run", resolved at landing
+    offs_t off = 0, LFoff_k = 0;
     bool thr_ok_k = true;
     // landing target
     uint32_t k0 = 0;
-    uint64_t offp = 0;
+    offs_t offp = 0;
     // per-step results
     uint32_t length = 0, doc = 0;
     uint64_t sample = 0;
@@ -167,6 +174,22 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t n_steps = 0, n_jumps = 0, n_pred = 0, n_rows = 0, n_dir = 0, n_err = 0;
 
     if (rd >= b.nreads || (threadIdx.x & 63) >= lpw) ph = P_DONE;
+#define STAND_ON(row)                                \
+    do {                                             \
+        if (COMPACT) {                               \
+            H_k = crow_H(row);                       \
+            LFrun_k = crow_LFrun(row);               \
+            LFoff_k = crow_LFoff(row);               \
+            thr_ok_k = crow_thr_ok(row);             \
+            room_k = crow_cums(row);                 \
+        } else {                                     \
+            H_k = row_H(row);                        \
+            LFrun_k = row_LFrun(row);                \
+            LFoff_k = (offs_t)row_LFoff(row);        \
+            thr_ok_k = row_thr_ok(row);              \
+            room_k = row_room(row);                  \
+        }                                            \
+    } while (0)
 #define LF_TARGET()                                                      \
     do {                                                                 \
         if (COMPACT)                                                     \
@@ -229,27 +252,15 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             Row ra;
             ra.q0 = g0;
             ra.q1 = g1;
-            const uint64_t len = COMPACT ? (uint64_t)crow_len(ra) : row_len(ra);
-            if (offp == OFF_END) offp = len - 1;  // predecessor landing: last position of this run
+            const offs_t len = COMPACT ? (offs_t)crow_len(ra) : (offs_t)row_len(ra);
+            if (offp == OFF_LAST) offp = (offs_t)len - 1;  // predecessor landing: last position of this run
             if (offp >= len) {  // LF image lies in a later run: skip this row
                 offp -= len;
                 k0++;
             } else {
                 k = k0;
                 off = offp;
-                if (COMPACT) {
-                    H_k = crow_H(ra);
-                    LFrun_k = crow_LFrun(ra);
-                    LFoff_k = crow_LFoff(ra);
-                    thr_ok_k = crow_thr_ok(ra);
-                    room_k = crow_cums(ra);
-                } else {
-                    H_k = row_H(ra);
-                    LFrun_k = row_LFrun(ra);
-                    LFoff_k = row_LFoff(ra);
-                    thr_ok_k = row_thr_ok(ra);
-                    room_k = row_room(ra);
-                }
+                STAND_ON(ra);
                 do_step = true;
             }
         } else if (ph == P_FAT) {
@@ -303,9 +314,15 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 length = 0;
                 sample = ix.init_sample;  // compute_ms_pml.cpp:575
                 doc = ix.init_doc;        // :298 / :634
-                k0 = ix.init_k;           // pos = bwt_size() - 1   (:243 / :574)
-                offp = ix.init_off;
-                wbase = ~0ull;            // no characters loaded yet
+                // pos = bwt_size() - 1 (:243 / :574): the same row for every read, kept in the
+                // kernel arguments -- the walk stands on it at once and fetches its first characters
+                k = ix.init_k;
+                off = (offs_t)ix.init_off;
+                STAND_ON(ix.init_row);
+                {
+                    const uint64_t end4 = (base + m + 3) & ~3ull;  // window ends past the last character
+                    wbase = end4 >= 32 ? end4 - 32 : 0;
+                }
                 ob_lo = ob_hi = db_lo = db_hi = 0;
                 if (want_class) {
                     const uint32_t w = (uint32_t)b.bin_width;
@@ -316,7 +333,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     bin_max = above = below = 0;
                     sum_max = 0;
                 }
-                ph = P_LAND;
+                ph = P_CHARS;
             }
         } else if (ph == P_AUX) {
             // only the inconsistent-threshold case of Appendix C1 comes here: side data of the
@@ -341,9 +358,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             const bool has_succ = jdir < qend;  // rnk < number_of_letter(c)   (:259)
             const uint32_t trun = jr_THRrun(e);
             // pos < thr, with thr = n + 1 when there is no successor (:254, :270)
-            const bool below_thr = !has_succ || (k < trun) || (k == trun && off < jr_THRoff(e));
+            const bool below_thr = !has_succ || (k < trun) || (k == trun && off < (offs_t)jr_THRoff(e));
             const uint32_t srun = jr_sLFrun(e);
-            const uint64_t soff = jr_sLFoff(e);
+            const offs_t soff = (offs_t)jr_sLFoff(e);
             length = 0;
             aux_take = 0;
             peek = false;
@@ -359,7 +376,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     aux_take = 1;
                     const bool ps = jr_psame(e);
                     k0 = ps ? srun : srun - 1;
-                    offp = ps ? soff - 1 : OFF_END;
+                    offp = ps ? soff - 1 : OFF_LAST;
                     Hland = ps ? jr_Hs(e) : jr_Hp(e);
                     peek = ps;  // the exact offset is only known when it stays in run sLFrun
                 }
@@ -381,7 +398,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     aux_take = 1;
                     const bool ps = jr_psame(e);
                     k0 = ps ? srun : srun - 1;
-                    offp = ps ? soff - 1 : OFF_END;
+                    offp = ps ? soff - 1 : OFF_LAST;
                 }
             }
             if (AUX && quirk && below_thr && off > 0) {
@@ -412,7 +429,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                         if (DOC) doc = ix.doc_at0;  // :641-642
                     }
                     k0 = li.frun;  // LF(pos, c) = F[c] + 0
-                    offp = li.foff;
+                    offp = (offs_t)li.foff;
                     do_emit = true;
                 } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
                     length++;
