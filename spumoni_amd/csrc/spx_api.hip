@@ -103,8 +103,6 @@ void spx_index_free(spx_index* ix) {
     if (ix->fat) (void)hipFree(ix->fat);
     if (ix->dirdocs) (void)hipFree(ix->dirdocs);
     if (ix->rundocs) (void)hipFree(ix->rundocs);
-    if (ix->fat_samples) (void)hipFree(ix->fat_samples);
-    if (ix->fat_docs) (void)hipFree(ix->fat_docs);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);
     if (ix->samples) (void)hipFree(ix->samples);
     if (ix->dirrows) (void)hipFree(ix->dirrows);

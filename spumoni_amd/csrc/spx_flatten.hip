@@ -221,19 +221,16 @@ __global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const Letter
 }
 
 // fat[lid][b] = copy of the jump row of the first c-run at or after block b
-__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, uint64_t total, JumpRow* fat) {
-    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
-    if (i < total) fat[i] = dirrows[cnt[i]];
-}
-
-// side data of every fat slot: the samples / doc ids of the directory position it copies
-__global__ void k_fill_fat_aux(const uint32_t* cnt, const SamplePair* samples, const uint32_t* dirdocs,
-                               uint64_t total, SamplePair* fat_samples, uint32_t* fat_docs) {
+// samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride)
+__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const SamplePair* samples,
+                           const uint32_t* dirdocs, uint64_t total, char* fat, uint32_t stride, uint32_t doc_off) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= total) return;
     const uint32_t j = cnt[i];
-    if (fat_samples) fat_samples[i] = samples[j];
-    if (fat_docs) fat_docs[i] = dirdocs[j];
+    char* slot = fat + i * stride;
+    *reinterpret_cast<JumpRow*>(slot) = dirrows[j];
+    if (samples) *reinterpret_cast<SamplePair*>(slot + sizeof(JumpRow)) = samples[j];
+    if (dirdocs) *reinterpret_cast<uint32_t*>(slot + doc_off) = dirdocs[j];
 }
 
 __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
@@ -401,7 +398,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     const bool has_ms = d_ssa && d_esa;
     const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
-    const double per_slot = 32 + (has_ms ? 16 : 0) + (docs ? 4 : 0) + 4 /* cnt scratch */;
+    const uint32_t fat_doc_off = has_ms ? 48 : 32;
+    const uint32_t fat_stride = docs ? fat_doc_off + 16 : (has_ms ? 48 : 32);  // 16-byte granules
+    const double per_slot = fat_stride + 4 /* cnt scratch */;
     uint32_t bshift = 0;
     while ((3u << bshift) < nletters && bshift < 16) bshift++;
     if (const char* e = getenv("SPX_FAT_BSHIFT")) {  // test / experiment knob: force 2^bshift runs per block
@@ -424,12 +423,11 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     SPX_HIP(cnt.alloc(nfat * 4 + 64));
     k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, bshift,
                                             nblk, cnt.as<uint32_t>());
-    SPX_HIP(hipMalloc((void**)&ix->fat, (nfat + 2) * sizeof(JumpRow)));
-    k_fill_fat<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, nfat, ix->fat);
+    SPX_HIP(hipMalloc((void**)&ix->fat, (nfat + 2) * (uint64_t)fat_stride));
     SPX_HIP(hipMalloc((void**)&ix->q_alloc, (r + 1 + Q_PAD) * 4));
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
-    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * sizeof(JumpRow) +
+    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
                      (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 8 : 0);
     uint64_t last_esa = 0, last_de = 0, first_ds = 0;
     if (d_ssa && d_esa) {
@@ -438,18 +436,12 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, ix->samples,
                                                    ix->ss_by_run);
         SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipMalloc((void**)&ix->fat_samples, (nfat + 2) * sizeof(SamplePair)));
-        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8 + (nfat + 2) * sizeof(SamplePair);
+        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8;
         ix->has_samples = true;
     }
     ix->has_docs = docs;
-    if (docs) {
-        SPX_HIP(hipMalloc((void**)&ix->fat_docs, (nfat + 2) * 4));
-        bytes += (nfat + 2) * 4;
-    }
-    if (ix->fat_samples || ix->fat_docs)
-        k_fill_fat_aux<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->samples, ix->dirdocs, nfat,
-                                                       ix->fat_samples, ix->fat_docs);
+    k_fill_fat<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->samples, ix->dirdocs, nfat, ix->fat,
+                                               fat_stride, fat_doc_off);
     if (docs) {
         SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
@@ -475,8 +467,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.ss_by_run = ix->ss_by_run;
     v.dirdocs = ix->dirdocs;
     v.rundocs = ix->rundocs;
-    v.fat_samples = ix->fat_samples;
-    v.fat_docs = ix->fat_docs;
+    v.fat_stride = fat_stride;
+    v.fat_doc_off = fat_doc_off;
     v.letters = ix->letters;
     v.text = nullptr;
     v.n_text = 0;

@@ -56,13 +56,11 @@ struct spx_index {
     spx::Row* rows = nullptr;
     uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
     spx::JumpRow* dirrows = nullptr;
-    spx::JumpRow* fat = nullptr;
+    char* fat = nullptr;  // slots of DevIndex::fat_stride bytes
     spx::SamplePair* samples = nullptr;
     uint64_t* ss_by_run = nullptr;
     uint32_t* dirdocs = nullptr;
     uint32_t* rundocs = nullptr;
-    spx::SamplePair* fat_samples = nullptr;
-    uint32_t* fat_docs = nullptr;
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;
     uint64_t n_text = 0;

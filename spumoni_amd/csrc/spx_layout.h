@@ -154,14 +154,17 @@ struct SamplePair {  // MS mode, directory order: entry j = {samples_start[Q[j]]
 struct DevIndex {
     const Row* rows;            // r + ROW_PAD rows; row r is the "pos == n" sentinel
     const JumpRow* dirrows;     // r + 1 (+ pad) jump rows, (letter, run) order
-    const JumpRow* fat;         // [nletters][nblk] first-c-run-at-or-after-block jump rows
+    const char* fat;            // [nletters][nblk] slots of the first c-run at or after the block (see fat_stride)
     const uint32_t* Q;          // directory; Q[-1] and Q[r .. r + Q_PAD) are readable
     const SamplePair* samples;  // r + 1 (+ pad) entries in directory order, or nullptr
     const uint64_t* ss_by_run;  // samples_start by run index (+ pad) or nullptr
     const uint32_t* dirdocs;    // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16, or nullptr
     const uint32_t* rundocs;    // by run index k: docS[k] | docE[k] << 16, or nullptr
-    const SamplePair* fat_samples;  // samples[] entry of every fat slot (MS) or nullptr
-    const uint32_t* fat_docs;       // dirdocs[] entry of every fat slot (doc array) or nullptr
+    // a fat slot is fat_stride bytes: the JumpRow, then (index with SA samples) the SamplePair of
+    // that directory position at +32, then (index with a document array) its dirdocs word at
+    // fat_doc_off -- everything a jump needs in MS / doc mode sits in the one line the JumpRow is in
+    uint32_t fat_stride;   // 32, 48 or 64
+    uint32_t fat_doc_off;  // 32 (no samples) or 48
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;

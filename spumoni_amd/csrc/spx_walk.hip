@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             p0 = rows_b + (uint64_t)k0 * sizeof(Row);
         } else if (ph == P_FAT) {
             fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
-            p0 = fat_b + fidx * sizeof(JumpRow);
+            p0 = fat_b + fidx * ix.fat_stride;
         } else if (ph == P_DIR) {
             p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
         } else if (ph == P_QS) {
@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         // end_runs_doc[previous c-run]}, from the fat copies (P_FAT) or by directory position
         SamplePair sp{0, 0};
         if (MODE == SPX_MODE_MS) {
-            const SamplePair* ps = (ph == P_FAT) ? ix.fat_samples + fidx
+            const SamplePair* ps = (ph == P_FAT) ? reinterpret_cast<const SamplePair*>(p0 + sizeof(JumpRow))
                                                  : ix.samples + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
             sp = *ps;
         }
         uint32_t dd = 0;
         if (DOC) {
             const uint32_t* pd = (ph == P_SAMP)  ? ix.rundocs + k
-                                 : (ph == P_FAT) ? ix.fat_docs + fidx
+                                 : (ph == P_FAT) ? reinterpret_cast<const uint32_t*>(p0 + ix.fat_doc_off)
                                                  : ix.dirdocs + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
             dd = *pd;
         }
