@@ -101,6 +101,7 @@ void spx_index_free(spx_index* ix) {
     (void)hipSetDevice(ix->device);
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->fat) (void)hipFree(ix->fat);
+    if (ix->fat_j) (void)hipFree(ix->fat_j);
     if (ix->dirdocs) (void)hipFree(ix->dirdocs);
     if (ix->rundocs) (void)hipFree(ix->rundocs);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);

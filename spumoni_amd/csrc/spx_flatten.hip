@@ -223,14 +223,17 @@ __global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const Letter
 // fat[lid][b] = copy of the jump row of the first c-run at or after block b
 // samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride)
 __global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const SamplePair* samples,
-                           const uint32_t* dirdocs, uint64_t total, char* fat, uint32_t stride, uint32_t doc_off) {
-    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t j = cnt[i];
-    char* slot = fat + i * stride;
-    *reinterpret_cast<JumpRow*>(slot) = dirrows[j];
-    if (samples) *reinterpret_cast<SamplePair*>(slot + sizeof(JumpRow)) = samples[j];
-    if (dirdocs) *reinterpret_cast<uint32_t*>(slot + doc_off) = dirdocs[j];
+                           const uint32_t* dirdocs, uint64_t total, char* fat, uint32_t stride, uint32_t doc_off,
+                           const uint2* qrange, uint32_t nblk, int force_esc) {
+    // grid-stride: the table can have more than 2^32 slots, a HIP grid cannot have that many threads
+    for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * TPB) {
+        const uint32_t j = cnt[i];
+        char* slot = fat + i * stride;
+        const uint2 qr = qrange[i / nblk];
+        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(dirrows[j], j >= qr.y, j <= qr.x, force_esc != 0);
+        if (samples) *reinterpret_cast<SamplePair*>(slot + sizeof(FatRow)) = samples[j];
+        if (dirdocs) *reinterpret_cast<uint32_t*>(slot + doc_off) = dirdocs[j];
+    }
 }
 
 __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
@@ -398,8 +401,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     const bool has_ms = d_ssa && d_esa;
     const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
-    const uint32_t fat_doc_off = has_ms ? 48 : 32;
-    const uint32_t fat_stride = docs ? fat_doc_off + 16 : (has_ms ? 48 : 32);  // 16-byte granules
+    const uint32_t fat_row_bytes = sizeof(FatRow);
+    const uint32_t fat_doc_off = fat_row_bytes + (has_ms ? 16 : 0);
+    const uint32_t fat_stride = fat_doc_off + (docs ? 16 : 0);  // 16-byte granules
     const double per_slot = fat_stride + 4 /* cnt scratch */;
     uint32_t bshift = 0;
     while ((3u << bshift) < nletters && bshift < 16) bshift++;
@@ -440,13 +444,29 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         ix->has_samples = true;
     }
     ix->has_docs = docs;
-    k_fill_fat<<<nblocks(nfat), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->samples, ix->dirdocs, nfat, ix->fat,
-                                               fat_stride, fat_doc_off);
+    {
+        std::vector<uint2> qrange(nletters + 1, make_uint2(0, 0));
+        for (auto& li : hl)
+            if (li.lid != NO_LETTER) qrange[li.lid] = make_uint2(li.qbeg, li.qend);
+        DevBuf dq;
+        SPX_HIP(dq.alloc((nletters + 1) * sizeof(uint2)));
+        SPX_HIP(hipMemcpyAsync(dq.p, qrange.data(), (nletters + 1) * sizeof(uint2), hipMemcpyHostToDevice, st));
+        const unsigned fat_grid = nfat / TPB + 1 < (1u << 22) ? (unsigned)(nfat / TPB + 1) : (1u << 22);
+        k_fill_fat<<<fat_grid, TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->samples, ix->dirdocs, nfat,
+                                                   ix->fat, fat_stride, fat_doc_off, dq.as<uint2>(), nblk,
+                                                   getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
+        SPX_HIP(hipGetLastError());
+        SPX_HIP(hipStreamSynchronize(st));
+    }
+    ix->fat_j = (uint32_t*)cnt.p;  // the block count table stays: it is fat_j
+    cnt.p = nullptr;
+    bytes += nfat * 4 + 64;
     if (docs) {
         SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
     }
 
+    SPX_HIP(hipGetLastError());  // a kernel of this function that failed to launch
     unsigned long long herr = 0;
     SPX_HIP(hipMemcpyAsync(&herr, err.p, 8, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipStreamSynchronize(st));
@@ -467,6 +487,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.ss_by_run = ix->ss_by_run;
     v.dirdocs = ix->dirdocs;
     v.rundocs = ix->rundocs;
+    v.fat_j = ix->fat_j;
     v.fat_stride = fat_stride;
     v.fat_doc_off = fat_doc_off;
     v.letters = ix->letters;

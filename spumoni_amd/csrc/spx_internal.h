@@ -57,6 +57,7 @@ struct spx_index {
     uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
     spx::JumpRow* dirrows = nullptr;
     char* fat = nullptr;  // slots of DevIndex::fat_stride bytes
+    uint32_t* fat_j = nullptr;
     spx::SamplePair* samples = nullptr;
     uint64_t* ss_by_run = nullptr;
     uint32_t* dirdocs = nullptr;

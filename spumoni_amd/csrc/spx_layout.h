@@ -24,8 +24,9 @@
 //        Hs, Hp   heads of the runs the two landings are in
 //        j        position of q in the (letter, run index) order
 //      dirrows[j]            one JumpRow per run, in (letter, run index) order
-//      fat[letter][k >> s]   a COPY of the JumpRow of the first c-run at or after
-//                            block k >> s: one gather answers most jumps outright.
+//      fat[letter][k >> s]   a 16-byte digest (FatRow) of the JumpRow of the first c-run at
+//                            or after block k >> s: one 16-byte gather answers most jumps
+//                            outright; fat_j[..] is that run's directory position.
 //      Q[j]                  run indices in (letter, run) order (4 B), to locate
 //                            the successor when the block holds c-runs before k.
 #pragma once
@@ -135,6 +136,34 @@ SPX_HD uint32_t jr_Hs(const JumpRow& d) { return (uint32_t)(d.d2 >> 49) & 0xff; 
 SPX_HD uint32_t jr_Hp(const JumpRow& d) { return (uint32_t)(d.d3 >> 32) & 0xff; }
 SPX_HD uint32_t jr_j(const JumpRow& d) { return (uint32_t)d.d3; }
 
+// What a fat slot holds: the JumpRow of the first c-run at or after its block, squeezed into ONE
+// 16-byte lane load (the walk runs at the chip's rate of 16-byte lane loads) --
+// the threshold run as a 20-bit distance below q, the two offsets in 16 bits, no j and no Hp.
+// `esc` marks a slot whose row does not fit; the walk then fetches the slot's directory position
+// from fat_j and reads the full JumpRow (it does the same when the slot's run lies before the
+// walk's run and the directory has to be scanned).
+// nosucc: the slot points past the letter's last run (no c-run at or after the block);
+// first: the slot's run is the letter's first run (a predecessor jump from it is undefined).
+struct alignas(16) FatRow {
+    uint64_t w0;  // q[32] | sLFrun[32] << 32
+    uint64_t w1;  // (q - THRrun)[20] | THRoff[16] << 20 | sLFoff[16] << 36 | Hs[8] << 52 |
+                  // psame << 60 | nosucc << 61 | esc << 62 | first << 63
+};
+SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_esc) {
+    const uint32_t q = (uint32_t)f.d0, trun = (uint32_t)(f.d0 >> 32);
+    const uint64_t toff = f.d1 & MASK40, soff = f.d2 & MASK40;
+    const uint32_t srun = (uint32_t)(f.d1 >> 40) | ((uint32_t)((f.d2 >> 40) & 0xff) << 24);
+    const uint64_t dthr = (nosucc || trun > q) ? 0 : (uint64_t)q - trun;
+    const bool esc = force_esc || soff >= (1u << 16) ||
+                     (!nosucc && (trun > q || dthr >= (1u << 20) || toff >= (1u << 16)));
+    FatRow h;
+    h.w0 = (uint64_t)q | ((uint64_t)srun << 32);
+    h.w1 = (dthr & 0xfffff) | ((toff & 0xffff) << 20) | ((soff & 0xffff) << 36) | (((f.d2 >> 49) & 0xff) << 52) |
+           (((f.d2 >> 48) & 1) << 60) | ((uint64_t)(nosucc ? 1 : 0) << 61) | ((uint64_t)(esc ? 1 : 0) << 62) |
+           ((uint64_t)(first ? 1 : 0) << 63);
+    return h;
+}
+
 // per byte value c: everything the walk needs that depends only on the letter
 struct alignas(16) LetterInfo {
     uint32_t lid;    // dense letter id, NO_LETTER if number_of_letter(c) == 0
@@ -160,11 +189,12 @@ struct DevIndex {
     const uint64_t* ss_by_run;  // samples_start by run index (+ pad) or nullptr
     const uint32_t* dirdocs;    // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16, or nullptr
     const uint32_t* rundocs;    // by run index k: docS[k] | docE[k] << 16, or nullptr
-    // a fat slot is fat_stride bytes: the JumpRow, then (index with SA samples) the SamplePair of
-    // that directory position at +32, then (index with a document array) its dirdocs word at
-    // fat_doc_off -- everything a jump needs in MS / doc mode sits in the one line the JumpRow is in
-    uint32_t fat_stride;   // 32, 48 or 64
-    uint32_t fat_doc_off;  // 32 (no samples) or 48
+    // a fat slot is fat_stride bytes: the FatRow, then (index with SA samples) the SamplePair of
+    // that directory position at +16, then (index with a document array) its dirdocs word at
+    // fat_doc_off -- everything a jump needs in MS / doc mode sits in the line the FatRow is in
+    const uint32_t* fat_j; // directory position of every slot's run
+    uint32_t fat_stride;   // 16, 32 or 48
+    uint32_t fat_doc_off;  // 16 (no samples) or 32
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;

@@ -17,10 +17,12 @@
 //   P_READ   offsets[rd], offsets[rd+1]   16 B  (next read of this lane)
 //   P_CHARS  32 characters of the read    32 B  (refill, every <= 32 steps)
 //   P_LAND   rows[k0]                     16 B  (run the LF step lands in)
-//   P_FAT    fat[letter][k >> bshift]     32 B  (jump row of the first c-run at or
-//                                                after the block: usually THE answer)
+//   P_FAT    fat[letter][k >> bshift]     16 B  (digest of the jump row of the first c-run
+//                                                at or after the block: usually THE answer)
+//   P_FATJ   fat_j[letter][k >> bshift]    4 B  (only if the digest does not hold the row, or
+//                                                the block holds c-runs < k: where to go on)
 //   P_QS     Q[j .. j+8)                  32 B  (only if the block holds c-runs < k)
-//   P_DIR    dirrows[j]                   32 B  (only after P_QS)
+//   P_DIR    dirrows[j]                   32 B  (only after P_FATJ / P_QS)
 //   P_AUX / P_SAMP                              (MS samples / document ids)
 //
 // then consumes it and moves to the next phase.  Because the load site is
@@ -44,7 +46,8 @@ enum : uint32_t {
     P_DIR = 5,
     P_AUX = 6,
     P_SAMP = 7,
-    P_DONE = 8
+    P_FATJ = 8,
+    P_DONE = 9
 };
 
 constexpr int WALK_TPB = 256;
@@ -133,6 +136,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     const char* const rows_b = reinterpret_cast<const char*>(ix.rows);
     const char* const dir_b = reinterpret_cast<const char*>(ix.dirrows);
     const char* const fat_b = reinterpret_cast<const char*>(ix.fat);
+    const char* const fatj_b = reinterpret_cast<const char*>(ix.fat_j);
+    bool fat_found = false;  // P_FAT -> P_FATJ: the slot's run IS the successor (its row did not fit 16 bytes)
+    constexpr uint32_t FAT_ROW = sizeof(FatRow);
     const char* const q_b = reinterpret_cast<const char*>(ix.Q);
     const char* const seq_b = reinterpret_cast<const char*>(b.seqs);
     const char* const off_b = reinterpret_cast<const char*>(b.offs);
@@ -207,6 +213,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else if (ph == P_FAT) {
             fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
             p0 = fat_b + fidx * ix.fat_stride;
+        } else if (ph == P_FATJ) {
+            fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
+            p0 = fatj_b + ((fidx * 4) & ~15ull);  // the aligned 16 bytes that hold fat_j[fidx]
         } else if (ph == P_DIR) {
             p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
         } else if (ph == P_QS) {
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else {
             p0 = rows_b;
         }
-        const bool wide = (ph == P_FAT) | (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS);
+        const bool wide = (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS);
         const V16 ga = *reinterpret_cast<const V16*>(p0);
         V16 gb{0, 0, 0, 0};
         if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
@@ -229,7 +238,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         // end_runs_doc[previous c-run]}, from the fat copies (P_FAT) or by directory position
         SamplePair sp{0, 0};
         if (MODE == SPX_MODE_MS) {
-            const SamplePair* ps = (ph == P_FAT) ? reinterpret_cast<const SamplePair*>(p0 + sizeof(JumpRow))
+            const SamplePair* ps = (ph == P_FAT) ? reinterpret_cast<const SamplePair*>(p0 + FAT_ROW)
                                                  : ix.samples + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
             sp = *ps;
         }
@@ -240,8 +249,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                                                  : ix.dirdocs + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
             dd = *pd;
         }
-        const uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
-        const uint64_t g2 = u64of(gb.x, gb.y), g3 = u64of(gb.z, gb.w);
+        uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
+        uint64_t g2 = u64of(gb.x, gb.y), g3 = u64of(gb.z, gb.w);
 
         // ---- consume ---------------------------------------------------------
         bool do_emit = false;    // a character's result is final -> write it and advance
@@ -265,16 +274,33 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             }
         } else if (ph == P_FAT) {
             n_dir++;
-            JumpRow e;
-            e.d0 = g0;
-            e.d2 = g2;
-            e.d3 = g3;
-            const uint32_t ej = jr_j(e);
+            const uint32_t hq = (uint32_t)g0;
+            const bool nosucc = (g1 >> 61) & 1, esc = (g1 >> 62) & 1;
             // the block's first c-run is the successor unless it lies before k (or is k
             // itself when the walk sits on a c-run: byte >= 128, Appendix C1)
-            if (ej >= qend || jr_q(e) > k || (quirk && jr_q(e) == k)) {
-                jdir = ej;
+            fat_found = nosucc || hq > k || (quirk && hq == k);
+            if (fat_found && !esc && !quirk) {
+                // the 16 bytes are the whole answer: spread them into JumpRow form for the decision
+                // below (j is not known and not needed: only its place in [qbeg, qend] matters)
+                const uint64_t w0 = g0, w1 = g1;
+                const uint32_t srun = (uint32_t)(w0 >> 32);
+                g0 = (uint64_t)hq | ((uint64_t)(hq - (uint32_t)(w1 & 0xfffff)) << 32);
+                g1 = ((w1 >> 20) & 0xffff) | ((uint64_t)(srun & 0xffffff) << 40);
+                g2 = ((w1 >> 36) & 0xffff) | ((uint64_t)(srun >> 24) << 40) | (((w1 >> 60) & 1) << 48) |
+                     (((w1 >> 52) & 0xff) << 49);
+                jdir = nosucc ? qend : (((w1 >> 63) & 1) ? qbeg : qbeg + 1);
                 do_decide = true;
+            } else {
+                ph = P_FATJ;  // need the slot's directory position: full row, or a scan from there
+            }
+        } else if (ph == P_FATJ) {
+            n_dir++;
+            const uint32_t sel = (uint32_t)fidx & 3;
+            const uint64_t gsel = (sel & 2) ? g1 : g0;
+            const uint32_t ej = (sel & 1) ? (uint32_t)(gsel >> 32) : (uint32_t)gsel;
+            if (fat_found) {
+                jdir = ej;
+                ph = P_DIR;
             } else {
                 jdir = ej + 1;  // scan the directory from the next c-run on
                 ph = P_QS;
@@ -377,7 +403,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     const bool ps = jr_psame(e);
                     k0 = ps ? srun : srun - 1;
                     offp = ps ? soff - 1 : OFF_LAST;
-                    Hland = ps ? jr_Hs(e) : jr_Hp(e);
+                    Hland = jr_Hs(e);  // only looked at when the landing stays in run sLFrun (peek)
                     peek = ps;  // the exact offset is only known when it stays in run sLFrun
                 }
             } else {
@@ -703,11 +729,13 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
         SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
         ix->num_cus = prop.multiProcessorCount;
     }
-    // Occupancy target: 12 waves per CU.  Measured on C3 (tools/sweep.py): 262 / 478 / 612 /
-    // 597 / 565 M reads/s at 4 / 8 / 12 / 16 / 20 waves per CU -- past ~200 k lanes more
-    // chains only add queueing in front of the same HBM line-fill rate.
+    // Occupancy target: 20 waves per CU (five per SIMD, what the kernel's registers allow).
+    // Measured on C3 (tools/ab.sh): 911 / 1001 / 1026 M reads/s at 12 / 16 / 20 waves per CU.
+    // (With 32-byte fat rows -- two 16-byte lane loads per jump -- 12 was the optimum, 971 / 935 /
+    // 914: the kernel sits at the chip's rate of ~80 G 16-byte lane loads per second, and more
+    // chains only lengthened the queue.)
     int occ = ix->occ_blocks[slot];
-    const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : 12;
+    const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : 20;
     int want = target_waves / (WALK_TPB / 64);
     if (want < 1) want = 1;
     if (want < occ) occ = want;

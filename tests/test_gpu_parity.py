@@ -246,12 +246,15 @@ def test_limits_are_enforced(gpu):
         ix.query_host(capi.SPX_MODE_PML, rd, offs, want_docs=True)
 
 
-@pytest.mark.parametrize("bshift,wide_rows", [(0, 0), (2, 1), (5, 0), (9, 1)])
-def test_every_directory_block_size(gpu, oracle_mod, bshift, wide_rows, monkeypatch):
+@pytest.mark.parametrize("bshift,wide_rows,all_esc", [(0, 0, 0), (2, 1, 0), (5, 0, 0), (9, 1, 0), (0, 0, 1), (3, 1, 1)])
+def test_every_directory_block_size(gpu, oracle_mod, bshift, wide_rows, all_esc, monkeypatch):
     """The fat-table block size is chosen from the free memory; force it from 1 to 512 runs per
     block so that the direct answer, the one-window and the multi-window directory scans all run
-    (with both row encodings)."""
+    (with both row encodings); all_esc marks every 16-byte fat digest as not holding its row, so
+    that every jump goes through fat_j and the full JumpRow."""
     monkeypatch.setenv("SPX_FAT_BSHIFT", str(bshift))
+    if all_esc:
+        monkeypatch.setenv("SPX_FAT_ALL_ESC", "1")
     if wide_rows:
         monkeypatch.setenv("SPX_ROWS_WIDE", "1")
     for seed, letters in ((61, DNA), (62, [3, 4, 5, 90, 127, 128, 129, 200, 255])):
@@ -266,7 +269,9 @@ def test_every_directory_block_size(gpu, oracle_mod, bshift, wide_rows, monkeypa
 
 def test_long_runs_and_far_thresholds(gpu, oracle_mod):
     """Runs of 2^16 and more (the index then keeps the general row encoding instead of the compact
-    one) and a letter whose two runs -- and so a threshold and its run -- lie 1.5 * 2^20 runs apart."""
+    one, and offsets of 2^16 and more do not fit the 16-byte fat digest) and a letter whose two
+    runs -- and so a threshold and its run -- lie 1.5 * 2^20 runs apart (distance does not fit):
+    those slots take the escape path, the rest of the same index the 16-byte path."""
     rng = np.random.default_rng(5)
     acg = np.frombuffer(b"ACG", dtype=np.uint8)
     # (1) long runs among short ones
