@@ -102,10 +102,9 @@ void spx_index_free(spx_index* ix) {
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->fat) (void)hipFree(ix->fat);
     if (ix->fat_j) (void)hipFree(ix->fat_j);
-    if (ix->dirdocs) (void)hipFree(ix->dirdocs);
     if (ix->rundocs) (void)hipFree(ix->rundocs);
     if (ix->q_alloc) (void)hipFree(ix->q_alloc);
-    if (ix->samples) (void)hipFree(ix->samples);
+    if (ix->aux) (void)hipFree(ix->aux);
     if (ix->dirrows) (void)hipFree(ix->dirrows);
     if (ix->ss_by_run) (void)hipFree(ix->ss_by_run);
     if (ix->letters) (void)hipFree(ix->letters);

@@ -222,17 +222,15 @@ __global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const Letter
 
 // fat[lid][b] = copy of the jump row of the first c-run at or after block b
 // samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride)
-__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const SamplePair* samples,
-                           const uint32_t* dirdocs, uint64_t total, char* fat, uint32_t stride, uint32_t doc_off,
-                           const uint2* qrange, uint32_t nblk, int force_esc) {
+__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Aux* aux, uint64_t total, char* fat,
+                           uint32_t stride, const uint2* qrange, uint32_t nblk, int force_esc) {
     // grid-stride: the table can have more than 2^32 slots, a HIP grid cannot have that many threads
     for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * TPB) {
         const uint32_t j = cnt[i];
         char* slot = fat + i * stride;
         const uint2 qr = qrange[i / nblk];
         *reinterpret_cast<FatRow*>(slot) = pack_fatrow(dirrows[j], j >= qr.y, j <= qr.x, force_esc != 0);
-        if (samples) *reinterpret_cast<SamplePair*>(slot + sizeof(FatRow)) = samples[j];
-        if (dirdocs) *reinterpret_cast<uint32_t*>(slot + doc_off) = dirdocs[j];
+        if (aux) *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
     }
 }
 
@@ -245,6 +243,14 @@ __global__ void k_copy_q(const uint32_t* Qall, uint64_t r, uint32_t* q_alloc) {
 
 // MS samples in directory order: entry i = {samples_start[Q[i]], samples_last[Q[i-1]]};
 // plus samples_start by run index for the "byte >= 128 sitting on its own run" case
+// side data by directory position: samples pair and doc word packed into one 16-byte record
+__global__ void k_pack_aux(const SamplePair* samples, const uint32_t* dirdocs, uint64_t count, Aux* aux) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i >= count) return;
+    const SamplePair sp = samples ? samples[i] : SamplePair{0, 0};
+    aux[i] = pack_aux(sp.ss, sp.se, dirdocs ? dirdocs[i] : 0u);
+}
+
 __global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, const uint32_t* Qall, uint64_t r,
                           SamplePair* out, uint64_t* ss_by_run) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
@@ -360,8 +366,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     const bool docs = d_ds && d_de;
     SPX_HIP(hipMalloc((void**)&ix->rows, (r + ROW_PAD) * sizeof(Row)));
     SPX_HIP(hipMalloc((void**)&ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow)));
+    DevBuf dirdocs_tmp;  // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16; packed into aux below
     if (docs) {
-        SPX_HIP(hipMalloc((void**)&ix->dirdocs, (r + ROW_PAD) * 4));
+        SPX_HIP(dirdocs_tmp.alloc((r + ROW_PAD) * 4));
         SPX_HIP(hipMalloc((void**)&ix->rundocs, (r + ROW_PAD) * 4));
     }
     unsigned long long max_len = 0;
@@ -377,7 +384,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters,
-                                              H.as<uint8_t>(), r, n, compact, ix->rows, ix->dirrows, ix->dirdocs,
+                                              H.as<uint8_t>(), r, n, compact, ix->rows, ix->dirrows,
+                                              docs ? dirdocs_tmp.as<uint32_t>() : nullptr,
                                               ix->rundocs, err.as<unsigned long long>());
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, compact);
     SPX_HIP(hipStreamSynchronize(st));
@@ -402,8 +410,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     const bool has_ms = d_ssa && d_esa;
     const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
     const uint32_t fat_row_bytes = sizeof(FatRow);
-    const uint32_t fat_doc_off = fat_row_bytes + (has_ms ? 16 : 0);
-    const uint32_t fat_stride = fat_doc_off + (docs ? 16 : 0);  // 16-byte granules
+    const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs) ? (uint32_t)sizeof(Aux) : 0);
     const double per_slot = fat_stride + 4 /* cnt scratch */;
     uint32_t bshift = 0;
     while ((3u << bshift) < nletters && bshift < 16) bshift++;
@@ -432,18 +439,25 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
     uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
-                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 8 : 0);
+                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 4 : 0);
     uint64_t last_esa = 0, last_de = 0, first_ds = 0;
+    DevBuf samples_tmp;
     if (d_ssa && d_esa) {
-        SPX_HIP(hipMalloc((void**)&ix->samples, (r + 2) * sizeof(SamplePair)));
+        SPX_HIP(samples_tmp.alloc((r + 2) * sizeof(SamplePair)));
         SPX_HIP(hipMalloc((void**)&ix->ss_by_run, (r + 4) * 8));
-        k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, ix->samples,
+        k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, samples_tmp.as<SamplePair>(),
                                                    ix->ss_by_run);
         SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        bytes += (r + 2) * sizeof(SamplePair) + (r + 4) * 8;
+        bytes += (r + 4) * 8;
         ix->has_samples = true;
     }
     ix->has_docs = docs;
+    if (ix->has_samples || docs) {  // samples + doc words of a directory position in one record
+        SPX_HIP(hipMalloc((void**)&ix->aux, (r + 2) * sizeof(Aux)));
+        k_pack_aux<<<nblocks(r + 1), TPB, 0, st>>>(ix->has_samples ? samples_tmp.as<SamplePair>() : nullptr,
+                                                    docs ? dirdocs_tmp.as<uint32_t>() : nullptr, r + 1, ix->aux);
+        bytes += (r + 2) * sizeof(Aux);
+    }
     {
         std::vector<uint2> qrange(nletters + 1, make_uint2(0, 0));
         for (auto& li : hl)
@@ -452,9 +466,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(dq.alloc((nletters + 1) * sizeof(uint2)));
         SPX_HIP(hipMemcpyAsync(dq.p, qrange.data(), (nletters + 1) * sizeof(uint2), hipMemcpyHostToDevice, st));
         const unsigned fat_grid = nfat / TPB + 1 < (1u << 22) ? (unsigned)(nfat / TPB + 1) : (1u << 22);
-        k_fill_fat<<<fat_grid, TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->samples, ix->dirdocs, nfat,
-                                                   ix->fat, fat_stride, fat_doc_off, dq.as<uint2>(), nblk,
-                                                   getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
+        k_fill_fat<<<fat_grid, TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->aux, nfat, ix->fat, fat_stride,
+                                              dq.as<uint2>(), nblk, getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
         SPX_HIP(hipGetLastError());
         SPX_HIP(hipStreamSynchronize(st));
     }
@@ -483,25 +496,24 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.dirrows = ix->dirrows;
     v.fat = ix->fat;
     v.Q = ix->q_alloc + 1;
-    v.samples = ix->samples;
+    v.aux = ix->aux;
     v.ss_by_run = ix->ss_by_run;
-    v.dirdocs = ix->dirdocs;
     v.rundocs = ix->rundocs;
     v.fat_j = ix->fat_j;
     v.fat_stride = fat_stride;
-    v.fat_doc_off = fat_doc_off;
     v.letters = ix->letters;
     v.text = nullptr;
     v.n_text = 0;
     v.n = n;
     v.r = (uint32_t)r;
     v.compact = (uint32_t)compact;
+    v.nletters = nletters;
     v.nblk = nblk;
     v.bshift = bshift;
     v.init_k = (uint32_t)(r - 1);
     v.init_off = last_len - 1;
     SPX_HIP(hipMemcpy(&v.init_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost));
-    v.init_sample = ix->samples ? (last_esa + 1) % n : 0;
+    v.init_sample = ix->has_samples ? (last_esa + 1) % n : 0;
     v.init_doc = (uint32_t)last_de;
     v.doc_at0 = (uint32_t)first_ds;
     ix->device_bytes = bytes;

@@ -58,9 +58,8 @@ struct spx_index {
     spx::JumpRow* dirrows = nullptr;
     char* fat = nullptr;  // slots of DevIndex::fat_stride bytes
     uint32_t* fat_j = nullptr;
-    spx::SamplePair* samples = nullptr;
+    spx::Aux* aux = nullptr;
     uint64_t* ss_by_run = nullptr;
-    uint32_t* dirdocs = nullptr;
     uint32_t* rundocs = nullptr;
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;

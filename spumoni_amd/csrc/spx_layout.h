@@ -174,7 +174,25 @@ struct alignas(16) LetterInfo {
     uint64_t pad_;
 };
 
-struct SamplePair {  // MS mode, directory order: entry j = {samples_start[Q[j]], samples_last[Q[j-1]]}
+// Side data of directory position j, everything a jump to run Q[j] (or to the end of run Q[j-1])
+// hands out in MS / doc mode, in 16 bytes:
+//     a0: samples_start[Q[j]] [40] | samples_last[Q[j-1]] [0:24] << 40
+//     a1: samples_last[Q[j-1]] [24:40] | (start_runs_doc[Q[j]] | end_runs_doc[Q[j-1]] << 16) << 16
+// (fields of an index without samples / without a document array are zero)
+struct alignas(16) Aux {
+    uint64_t a0, a1;
+};
+SPX_HD Aux pack_aux(uint64_t ss, uint64_t se, uint32_t docs) {
+    Aux a;
+    a.a0 = (ss & MASK40) | ((se & 0xffffff) << 40);
+    a.a1 = ((se >> 24) & 0xffff) | ((uint64_t)docs << 16);
+    return a;
+}
+SPX_HD uint64_t aux_ss(const Aux& a) { return a.a0 & MASK40; }
+SPX_HD uint64_t aux_se(const Aux& a) { return (a.a0 >> 40) | ((a.a1 & 0xffff) << 24); }
+SPX_HD uint32_t aux_docs(const Aux& a) { return (uint32_t)(a.a1 >> 16); }
+
+struct SamplePair {  // flatten-time temporary: entry j = {samples_start[Q[j]], samples_last[Q[j-1]]}
     uint64_t ss;
     uint64_t se;
 };
@@ -185,22 +203,21 @@ struct DevIndex {
     const JumpRow* dirrows;     // r + 1 (+ pad) jump rows, (letter, run) order
     const char* fat;            // [nletters][nblk] slots of the first c-run at or after the block (see fat_stride)
     const uint32_t* Q;          // directory; Q[-1] and Q[r .. r + Q_PAD) are readable
-    const SamplePair* samples;  // r + 1 (+ pad) entries in directory order, or nullptr
+    const Aux* aux;             // r + 1 (+ pad) entries in directory order, or nullptr (PML-only, no docs)
     const uint64_t* ss_by_run;  // samples_start by run index (+ pad) or nullptr
-    const uint32_t* dirdocs;    // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16, or nullptr
     const uint32_t* rundocs;    // by run index k: docS[k] | docE[k] << 16, or nullptr
-    // a fat slot is fat_stride bytes: the FatRow, then (index with SA samples) the SamplePair of
-    // that directory position at +16, then (index with a document array) its dirdocs word at
-    // fat_doc_off -- everything a jump needs in MS / doc mode sits in the line the FatRow is in
+    // a fat slot is fat_stride bytes: the FatRow, then (index with SA samples or documents) the Aux
+    // of that directory position at +16 -- everything a jump needs in MS / doc mode sits in the
+    // same 32 aligned bytes
     const uint32_t* fat_j; // directory position of every slot's run
-    uint32_t fat_stride;   // 16, 32 or 48
-    uint32_t fat_doc_off;  // 16 (no samples) or 32
+    uint32_t fat_stride;   // 16 or 32
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;
     uint64_t n;
     uint32_t r;
     uint32_t compact;   // rows use the compact encoding (every run shorter than 2^16)
+    uint32_t nletters;  // byte values that occur in the BWT
     uint32_t nblk;      // blocks per letter in fat (= (r >> bshift) + 2)
     uint32_t bshift;    // log2(runs per directory block)
     uint32_t init_k;    // run of position n-1  (= r-1)

@@ -237,18 +237,18 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         // {samples_start[q], samples_last[previous c-run]} and doc ids {start_runs_doc[q],
         // end_runs_doc[previous c-run]}, from the fat copies (P_FAT) or by directory position
         SamplePair sp{0, 0};
-        if (MODE == SPX_MODE_MS) {
-            const SamplePair* ps = (ph == P_FAT) ? reinterpret_cast<const SamplePair*>(p0 + FAT_ROW)
-                                                 : ix.samples + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
-            sp = *ps;
-        }
         uint32_t dd = 0;
-        if (DOC) {
-            const uint32_t* pd = (ph == P_SAMP)  ? ix.rundocs + k
-                                 : (ph == P_FAT) ? reinterpret_cast<const uint32_t*>(p0 + ix.fat_doc_off)
-                                                 : ix.dirdocs + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
-            dd = *pd;
+        if (AUX) {  // one 16-byte record: from the fat slot itself (P_FAT) or by directory position
+            const Aux* pa = (ph == P_FAT) ? reinterpret_cast<const Aux*>(p0 + FAT_ROW)
+                                          : ix.aux + ((ph == P_DIR || ph == P_AUX) ? jdir : 0);
+            const Aux a = *pa;
+            if (MODE == SPX_MODE_MS) {
+                sp.ss = aux_ss(a);
+                sp.se = aux_se(a);
+            }
+            if (DOC) dd = aux_docs(a);
         }
+        if (DOC && ph == P_SAMP) dd = ix.rundocs[k];
         uint64_t g0 = u64of(ga.x, ga.y), g1 = u64of(ga.z, ga.w);
         uint64_t g2 = u64of(gb.x, gb.y), g3 = u64of(gb.z, gb.w);
 
@@ -734,8 +734,11 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     // (With 32-byte fat rows -- two 16-byte lane loads per jump -- 12 was the optimum, 971 / 935 /
     // 914: the kernel sits at the chip's rate of ~80 G 16-byte lane loads per second, and more
     // chains only lengthened the queue.)
+    // Match-heavy walks over small alphabets do best at 16 (DNA: 38.7 / 41.0 / 39.7 G steps/s), the
+    // variants that also fetch samples / document ids per jump at 12 (MS+doc 26.3 / 24.5 / 24.1).
     int occ = ix->occ_blocks[slot];
-    const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : 20;
+    const int auto_waves = (MODE == SPX_MODE_MS || DOC) ? 12 : (ix->view.nletters > 16 ? 20 : 16);
+    const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : auto_waves;
     int want = target_waves / (WALK_TPB / 64);
     if (want < 1) want = 1;
     if (want < occ) occ = want;

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spumoni_amd import capi, synth
 
 def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=3, lpw=0, no_class=False):
+    waves = waves or int(os.environ.get("SWEEP_WAVES", "0"))
     ix = capi.Index.from_raw(raw, 0)
     if waves: ix.set_option("waves_per_cu", waves)
     if lpw: ix.set_option("lanes_per_wave", lpw); tag = f"{tag} lanes/wave={lpw}"
