@@ -158,8 +158,12 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
         const uint64_t rbeg = a.offs[live ? rd : a.nreads];
         const uint64_t rend = a.offs[live ? rd + 1 : a.nreads];
         const uint64_t g0 = __shfl(rbeg, 0), g1 = __shfl(rend, 63);
+        // PASS 0 counts, PASS 1 writes the digest at its final place (out_offs), PASS 2 does both in one
+        // go: counts, and the minimizer bytes parked at the read's INPUT offset in a scratch buffer
+        // (k_digest_unstash moves them once the offsets are known) -- the reads are digested once
         uint64_t ob = 0;
         if (PASS == 1 && live) ob = a.out_offs[rd];
+        if (PASS == 2) ob = rbeg;
         // the lane's walk state
         uint32_t filled = 0, kmer = 0, cnt = 0, last = 0, acc = 0, nacc = 0;
         bool have = false;
@@ -235,6 +239,8 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                     } else if (em) {
                         if (KIND == SPX_DIGEST_PROMOTED) {
                             push_byte(mn > 2 ? mn : mn + 3);
+                        } else if (PASS == 2) {
+                            push_byte(mn);  // one byte per minimizer; spelled out by k_digest_unstash
                         } else {
                             const uint32_t code_min = mn ^ a.xm;
                             for (uint32_t t = 0; t < k; ++t)
@@ -244,13 +250,85 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                 }
             }
         }
-        if (PASS == 1) {
+        if (PASS >= 1) {
             for (uint32_t j = 0; j < nacc; ++j) {
                 const uint64_t addr = ob + e - nacc + j;
                 a.out[addr] = (uint8_t)(acc >> (8 * (uint32_t)(addr & 3)));
             }
-        } else if (live) {
-            a.counts[rd + 1] = e * (KIND == SPX_DIGEST_DNA ? k : 1);
+        }
+        if (PASS != 1 && live) a.counts[rd + 1] = e * (KIND == SPX_DIGEST_DNA ? k : 1);
+    }
+}
+
+// Second half of the one-pass digestion: the minimizer bytes of read q wait at stash[offs[q] ..];
+// 64 consecutive reads go to one contiguous stretch of the output, so the wavefront assembles that
+// stretch in LDS (every lane fetches its read's bytes with 16-byte loads, -a spells the k-mers
+// out) and writes it with aligned 16-byte stores.
+constexpr uint32_t STAGE = 8192;
+
+template <int KIND>
+__global__ void __launch_bounds__(64) k_digest_unstash(const DigestArgs a, const uint8_t* stash) {
+    __shared__ uint4 stage16[STAGE / 16 + 2];
+    uint8_t* const stage = reinterpret_cast<uint8_t*>(stage16);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = a.k;
+    const uint32_t mult = KIND == SPX_DIGEST_DNA ? k : 1;
+    const uint64_t ngroups = (a.nreads + 63) / 64;
+    for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint64_t rd = grp * 64 + lane;
+        const bool live = rd < a.nreads;
+        const uint64_t src = a.offs[live ? rd : a.nreads];
+        const uint64_t dbeg = a.out_offs[live ? rd : a.nreads];
+        const uint64_t dend = a.out_offs[live ? rd + 1 : a.nreads];
+        const uint32_t nmin = (uint32_t)((dend - dbeg) / mult);  // minimizers of this read
+        const uint64_t d0 = __shfl(dbeg, 0), d1 = __shfl(dend, 63);
+        const uint64_t total = d1 - d0;
+        const uint32_t skew = (uint32_t)(d0 & 15);  // stretch index = skew + (address - d0): chunks align
+        // the stretch goes through LDS in windows of STAGE bytes (one window for 200 bp reads)
+        const uint64_t base = skew + (dbeg - d0);  // stretch index of this read's first byte
+        for (uint64_t w0 = 0; w0 < skew + total; w0 += STAGE) {
+            __syncthreads();
+            const uint64_t w1 = w0 + STAGE;
+            // minimizers of this read with a byte in the window
+            const uint64_t lo_b = base > w0 ? 0 : w0 - base, hi_b = w1 > base ? w1 - base : 0;
+            const uint32_t t_lo = (uint32_t)min<uint64_t>(lo_b / mult, nmin);
+            const uint32_t t_hi = (uint32_t)min<uint64_t>((hi_b + mult - 1) / mult, nmin);
+            if (t_lo < t_hi) {
+                const uint64_t s0 = src + t_lo, s1 = src + t_hi;
+                for (uint64_t c = s0 & ~15ull; c < s1; c += 16) {  // aligned 16-byte chunks of the stash
+                    const uint4 v = *reinterpret_cast<const uint4*>(stash + c);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint64_t g = c + j;
+                        if (g >= s0 && g < s1) {
+                            const uint32_t byte = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            const uint64_t r = base + (g - src) * mult;  // stretch index of its first byte
+                            if (KIND == SPX_DIGEST_PROMOTED) {
+                                stage[r - w0] = (uint8_t)byte;
+                            } else {
+                                const uint32_t code = byte ^ a.xm;
+                                for (uint32_t i = 0; i < k; ++i)
+                                    if (r + i >= w0 && r + i < w1)
+                                        stage[r + i - w0] = (uint8_t)"ACGT"[(code >> (2 * (k - 1 - i))) & 3];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // write: aligned 16-byte chunks, the partial ones at the two ends of the stretch byte by byte
+            uint8_t* const obase = a.out + (d0 - skew) + w0;
+            const uint64_t end = min<uint64_t>(skew + total, w1) - w0;  // bytes of this window
+            const uint64_t first = w0 == 0 ? skew : 0;                  // bytes before it that are not ours
+            for (uint64_t c = (uint64_t)lane * 16; c < end; c += 64 * 16) {
+                if (c >= first && c + 16 <= end) {
+                    *reinterpret_cast<uint4*>(obase + c) = stage16[c >> 4];
+                } else {
+                    for (uint32_t j = 0; j < 16; ++j)
+                        if (c + j >= first && c + j < end) obase[c + j] = stage[c + j];
+                }
+            }
         }
     }
 }
@@ -321,34 +399,47 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     if (ix->force_digest_kernel == 1) lanes = a.wsz <= 8;
     if (ix->force_digest_kernel == 2) lanes = false;
     const uint64_t cus = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256);
-    auto pass = [&](int which) {
-        if (lanes) {
-            const uint64_t groups = (nreads + 63) / 64;
-            const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
-            if (kind == SPX_DIGEST_PROMOTED) {
-                if (which == 0) k_digest_lanes<0, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
-                else k_digest_lanes<1, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
-            } else {
-                if (which == 0) k_digest_lanes<0, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
-                else k_digest_lanes<1, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
-            }
-        } else {
-            const size_t lds = 2 * (size_t)ring + 256;
-            const uint32_t grid = (uint32_t)(nreads < cus * 64 ? nreads : cus * 64);
-            if (which == 0) k_digest_wave<0><<<grid, 64, lds, st>>>(a);
-            else k_digest_wave<1><<<grid, 64, lds, st>>>(a);
-        }
+    auto scan_counts = [&]() -> int {  // counts -> offsets, in place
+        size_t tmp_bytes = 0;
+        SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
+        void* tmp = nullptr;
+        SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+        SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
+        SPX_HIP(hipFreeAsync(tmp, st));
+        return SPX_OK;
     };
-    pass(0);
-    SPX_HIP(hipGetLastError());
-    // counts -> offsets, in place
-    size_t tmp_bytes = 0;
-    SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
-    void* tmp = nullptr;
-    SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
-    SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
-    SPX_HIP(hipFreeAsync(tmp, st));
-    pass(1);
+    if (lanes) {
+        // one pass over the reads: minimizer bytes parked in a scratch buffer of the input's size,
+        // moved to their place once the offsets are known
+        uint8_t* stash = nullptr;
+        SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
+        const uint64_t groups = (nreads + 63) / 64;
+        const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
+        a.out = stash;
+        if (kind == SPX_DIGEST_PROMOTED)
+            k_digest_lanes<2, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
+        else
+            k_digest_lanes<2, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
+        SPX_HIP(hipGetLastError());
+        int rc = scan_counts();
+        if (rc != SPX_OK) return rc;
+        a.out = d_out;
+        const uint32_t grid2 = (uint32_t)(groups < cus * 16 ? groups : cus * 16);
+        if (kind == SPX_DIGEST_PROMOTED)
+            k_digest_unstash<SPX_DIGEST_PROMOTED><<<grid2, 64, 0, st>>>(a, stash);
+        else
+            k_digest_unstash<SPX_DIGEST_DNA><<<grid2, 64, 0, st>>>(a, stash);
+        SPX_HIP(hipGetLastError());
+        SPX_HIP(hipFreeAsync(stash, st));
+    } else {
+        const size_t lds = 2 * (size_t)ring + 256;
+        const uint32_t grid = (uint32_t)(nreads < cus * 64 ? nreads : cus * 64);
+        k_digest_wave<0><<<grid, 64, lds, st>>>(a);
+        SPX_HIP(hipGetLastError());
+        int rc = scan_counts();
+        if (rc != SPX_OK) return rc;
+        k_digest_wave<1><<<grid, 64, lds, st>>>(a);
+    }
     k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
