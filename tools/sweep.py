@@ -101,3 +101,42 @@ if which in ("fatdiv",):
             os.environ["SPX_FAT_DIV"] = str(d)
             run(f"fat div={d} mix 0.5", raw, seqs5, offs5, reps=3)
             run(f"fat div={d} random", raw, seqs0, offs0, reps=3)
+if which in ("realmin",):
+    # the C3 pipeline end to end on REAL data at small scale: 10-haplotype pangenome, every sequence
+    # digested (-m, k=4, w=11) on the GPU, BWT index of the digested text, 200 bp DNA reads digested
+    # and walked on the device (spx_digest_batch_device -> spx_query_batch_device, nothing leaves HBM)
+    t0 = time.time()
+    base = synth.random_genome(20_000_000, seed=1)
+    genomes = [base] + [synth.mutate(base, seed=s) for s in range(2, 11)]
+    dig = capi.digester(0)
+    parts = []
+    for g in genomes:
+        for seq in (g, synth.revcomp(g)):
+            d, _ = dig.digest_host(capi.SPX_DIGEST_PROMOTED, 4, 11, seq, np.array([0, seq.size], dtype=np.uint64))
+            parts.append(d.copy())
+    dtext = np.concatenate(parts)
+    text, _ = synth.pangenome_text(genomes)
+    print(f"DNA text {text.size/1e6:.0f} Mbp -> digested text {dtext.size/1e6:.1f} M minimizers in {time.time()-t0:.1f}s", flush=True)
+    t0 = time.time()
+    raw = synth.index_from_text(torch.from_numpy(dtext).cuda(), with_samples=False)
+    torch.cuda.synchronize(); print(f"index of the digested text: n={raw.n} r={raw.r} n/r={raw.n/raw.r:.2f} in {time.time()-t0:.1f}s", flush=True)
+    nreads, m = 10_000_000, 200
+    seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
+    d_seqs, d_offs = torch.from_numpy(seqs).cuda(), torch.from_numpy(offs).cuda()
+    ix = capi.Index.from_raw(raw, 0)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for rep in range(3):
+        e[0].record()
+        d_d, d_do = ix.digest_device(capi.SPX_DIGEST_PROMOTED, 4, 11, d_seqs, d_offs, nreads * m)
+        e[1].record()
+        total = int(d_do[-1].item())
+        d_len = torch.empty(total + 8, dtype=torch.int32, device="cuda")
+        d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda")
+        t1 = torch.cuda.Event(enable_timing=True); t1.record()
+        ix.query_device(capi.SPX_MODE_PML, d_d, d_do, total, d_lengths=d_len, d_class=d_cls, bin_width=50, max_value_thr=5)
+        e[2].record(); torch.cuda.synchronize()
+        st = ix.last_stats()
+        dg, wk = e[0].elapsed_time(e[1]), t1.elapsed_time(e[2])
+        print(f"real minimizer index, {nreads} x {m} bp DNA reads: digest {dg:.2f} ms + walk {wk:.2f} ms "
+              f"({total/nreads:.1f} minimizers/read, f_mis {st['jumps']/st['steps']:.3f}, {st['steps']/st['kernel_ms']/1e6:.1f} G steps/s) "
+              f"-> {nreads/(dg+wk)/1e3:.1f} M reads/s = {nreads*m/(dg+wk)/1e6:.1f} G bases/s", flush=True)
