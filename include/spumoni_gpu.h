@@ -131,6 +131,20 @@ int spx_query_batch_device(spx_index *ix, int mode, const uint8_t *d_seqs,
                            uint32_t *d_out_lengths, uint64_t *d_out_pointers,
                            uint32_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
                            uint64_t max_value_thr, void *stream);
+/* 16-bit outputs: the same two calls with out_lengths / out_docs as uint16_t arrays -- half
+ * the output bytes (the PCIe copy of the host form, the stores of the device form).  Every
+ * read must be shorter than 65536 characters (lengths and document ids then fit, cf. the
+ * widths row of the boundary table): the host form checks, the device form reports a longer
+ * read through spx_last_walk_stats (SPX_E_FORMAT).                              */
+int spx_query_batch16(spx_index *ix, int mode, const uint8_t *seqs, const uint64_t *offsets,
+                      uint64_t nreads, uint16_t *out_lengths, uint64_t *out_pointers,
+                      uint16_t *out_docs, spx_class *out_class, uint64_t bin_width,
+                      uint64_t max_value_thr);
+int spx_query_batch_device16(spx_index *ix, int mode, const uint8_t *d_seqs,
+                             const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
+                             uint16_t *d_out_lengths, uint64_t *d_out_pointers,
+                             uint16_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                             uint64_t max_value_thr, void *stream);
 /* Statistics + HIP-event kernel time of the most recent query on `ix`
  * (synchronises with that query).                                            */
 int spx_last_walk_stats(spx_index *ix, spx_walk_stats *out);

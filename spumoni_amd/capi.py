@@ -32,6 +32,8 @@ EXPORTS = [
     "spx_index_set_text",
     "spx_query_batch",
     "spx_query_batch_device",
+    "spx_query_batch16",
+    "spx_query_batch_device16",
     "spx_last_walk_stats",
     "spx_set_option",
     "spx_host_alloc",
@@ -101,6 +103,8 @@ def lib() -> C.CDLL:
         L.spx_index_set_text.argtypes = [vp, vp, u64, i32]
         L.spx_query_batch.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
         L.spx_query_batch_device.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
+        L.spx_query_batch16.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
+        L.spx_query_batch_device16.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
         L.spx_last_walk_stats.argtypes = [vp, C.POINTER(SpxWalkStats)]
         L.spx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.spx_host_alloc.restype = vp
@@ -205,18 +209,21 @@ class Index:
         _check(lib().spx_set_option(self._h, key.encode(), value))
 
     # -- queries, host buffers (numpy) --------------------------------------
-    def query_host(self, mode, seqs, offs, want_lengths=True, want_docs=False, classify=None):
+    def query_host(self, mode, seqs, offs, want_lengths=True, want_docs=False, classify=None, bits=32):
+        """bits=16: the 16-bit entry point (uint16 lengths / docs; reads shorter than 65536)."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         nreads = offs.size - 1
         tot = int(offs[-1]) if nreads > 0 else 0
-        lens = np.zeros(max(tot, 1), dtype=np.uint32) if want_lengths else None
+        vt = np.uint16 if bits == 16 else np.uint32
+        lens = np.zeros(max(tot, 1) + 8, dtype=vt) if want_lengths else None
         ptrs = np.zeros(max(tot, 1), dtype=np.uint64) if mode == SPX_MODE_MS else None
-        docs = np.zeros(max(tot, 1), dtype=np.uint32) if want_docs else None
+        docs = np.zeros(max(tot, 1) + 8, dtype=vt) if want_docs else None
         cls_ = np.zeros(max(nreads, 1), dtype=CLASS_DTYPE) if classify else None
         bw, thr = classify if classify else (0, 0)
-        _check(lib().spx_query_batch(self._h, mode, _np_ptr(seqs), _np_ptr(offs), nreads, _np_ptr(lens),
-                                     _np_ptr(ptrs), _np_ptr(docs), _np_ptr(cls_), bw, thr))
+        fn = lib().spx_query_batch16 if bits == 16 else lib().spx_query_batch
+        _check(fn(self._h, mode, _np_ptr(seqs), _np_ptr(offs), nreads, _np_ptr(lens),
+                  _np_ptr(ptrs), _np_ptr(docs), _np_ptr(cls_), bw, thr))
         out = {}
         if lens is not None:
             out["lengths"] = lens[:tot]
@@ -231,12 +238,15 @@ class Index:
     # -- queries, device buffers (torch tensors on self.device) -------------
     def query_device(self, mode, d_seqs, d_offs, total_chars, d_lengths=None, d_pointers=None, d_docs=None,
                      d_class=None, bin_width=0, max_value_thr=0, stream=None):
-        """Enqueue on `stream` (a torch.cuda.Stream or None = torch's current stream)."""
+        """Enqueue on `stream` (a torch.cuda.Stream or None = torch's current stream).  int16 / uint16
+        tensors for d_lengths / d_docs select the 16-bit entry point."""
         import torch
 
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         nreads = d_offs.numel() - 1
-        _check(lib().spx_query_batch_device(
+        narrow = any(t is not None and t.element_size() == 2 for t in (d_lengths, d_docs))
+        fn = lib().spx_query_batch_device16 if narrow else lib().spx_query_batch_device
+        _check(fn(
             self._h, mode, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars, _t_ptr(d_lengths),
             _t_ptr(d_pointers), _t_ptr(d_docs), _t_ptr(d_class), bin_width, max_value_thr,
             C.c_void_p(st.cuda_stream)))

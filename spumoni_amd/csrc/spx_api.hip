@@ -436,10 +436,11 @@ static int check_query(spx_index* ix, int mode, const void* seqs, const void* of
     return SPX_OK;
 }
 
-int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
-                           uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
-                           uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
-                           uint64_t bin_width, uint64_t max_value_thr, void* stream) {
+// narrow: d_out_lengths / d_out_docs are uint16_t arrays (the 16-bit entry points)
+static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
+                             uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
+                             uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
+                             uint64_t bin_width, uint64_t max_value_thr, void* stream, bool narrow) {
     int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs,
                          d_out_class, bin_width);
     if (rc != SPX_OK) return rc;
@@ -471,6 +472,7 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     a.bin_magic = bin_width > 1 ? (uint64_t)(~0ull / bin_width) + 1 : 0;
     a.max_value_thr = max_value_thr;
     a.counters = ix->counters;
+    a.narrow = narrow ? 1 : 0;
     SPX_HIP(hipEventRecord(ix->ev0, st));
     if (nreads > 0) {
         rc = launch_walk(ix, mode, a, total_chars, st);
@@ -488,42 +490,67 @@ int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const
     return SPX_OK;
 }
 
+int spx_query_batch_device(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
+                           uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
+                           uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
+                           uint64_t bin_width, uint64_t max_value_thr, void* stream) {
+    return query_device_impl(ix, mode, d_seqs, d_offsets, nreads, total_chars, d_out_lengths, d_out_pointers,
+                             d_out_docs, d_out_class, bin_width, max_value_thr, stream, false);
+}
+
+int spx_query_batch_device16(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
+                             uint64_t nreads, uint64_t total_chars, uint16_t* d_out_lengths,
+                             uint64_t* d_out_pointers, uint16_t* d_out_docs, spx_class* d_out_class,
+                             uint64_t bin_width, uint64_t max_value_thr, void* stream) {
+    return query_device_impl(ix, mode, d_seqs, d_offsets, nreads, total_chars, (uint32_t*)d_out_lengths,
+                             d_out_pointers, (uint32_t*)d_out_docs, d_out_class, bin_width, max_value_thr, stream,
+                             true);
+}
+
 // device side of the host-buffer queries: d_seq / d_off are resident (scratch), results go
-// through scratch slots 2..5 to the host buffers.  Caller holds host_mu.
+// through scratch slots 2..5 to the host buffers.  Caller holds host_mu.  width: bytes per length /
+// doc value in the host buffers (4, or 2 for the 16-bit entry points)
 static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const uint64_t* d_off, uint64_t nreads,
-                         uint64_t total, uint32_t* out_lengths, uint64_t* out_pointers, uint32_t* out_docs,
-                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr) {
+                         uint64_t total, void* out_lengths, uint64_t* out_pointers, void* out_docs,
+                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr, size_t width = 4) {
     void *dlen = nullptr, *dptr = nullptr, *ddoc = nullptr, *dcls = nullptr;
     int rc;
     if (out_lengths && (rc = ensure_scratch(ix, 2, (total + 1) * 4, &dlen)) != SPX_OK) return rc;
     if (out_pointers && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &dptr)) != SPX_OK) return rc;
     if (out_docs && (rc = ensure_scratch(ix, 4, (total + 1) * 4, &ddoc)) != SPX_OK) return rc;
     if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
-    rc = spx_query_batch_device(ix, mode, d_seq, d_off, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr,
-                                (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr);
+    rc = query_device_impl(ix, mode, d_seq, d_off, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr,
+                           (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr, width == 2);
     if (rc != SPX_OK) return rc;
     SPX_HIP(hipDeviceSynchronize());
-    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen, total * 4, hipMemcpyDeviceToHost));
+    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen, total * width, hipMemcpyDeviceToHost));
     if (out_pointers) SPX_HIP(hipMemcpy(out_pointers, dptr, total * 8, hipMemcpyDeviceToHost));
-    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc, total * 4, hipMemcpyDeviceToHost));
+    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc, total * width, hipMemcpyDeviceToHost));
     if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
     WalkCounters wc;
     SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
     if (wc.error) {
         set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
-                  "thresholds are inconsistent with the BWT)", wc.error);
+                  "thresholds are inconsistent with the BWT%s)", wc.error,
+                  width == 2 ? "; or a read of 65536 characters or more with 16-bit outputs" : "");
         return SPX_E_FORMAT;
     }
     return SPX_OK;
 }
 
-int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
-                    uint64_t nreads, uint32_t* out_lengths, uint64_t* out_pointers,
-                    uint32_t* out_docs, spx_class* out_class, uint64_t bin_width,
-                    uint64_t max_value_thr) {
-    int rc = check_query(ix, mode, seqs, offsets, out_lengths, out_pointers, out_docs, out_class,
-                         bin_width);
+static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets, uint64_t nreads,
+                           void* out_lengths, uint64_t* out_pointers, void* out_docs, spx_class* out_class,
+                           uint64_t bin_width, uint64_t max_value_thr, size_t width) {
+    int rc = check_query(ix, mode, seqs, offsets, (uint32_t*)out_lengths, out_pointers, (uint32_t*)out_docs,
+                         out_class, bin_width);
     if (rc != SPX_OK) return rc;
+    if (width == 2)
+        for (uint64_t q = 0; q < nreads; ++q)
+            if (offsets[q + 1] - offsets[q] >= 65536) {
+                set_error("read %llu has 65536 characters or more: use the 32-bit entry point",
+                          (unsigned long long)q);
+                return SPX_E_ARG;
+            }
     std::lock_guard<std::mutex> hg(ix->host_mu);  // one host-buffer query at a time per index
     SPX_HIP(hipSetDevice(ix->device));
     const uint64_t total = nreads ? offsets[nreads] : 0;
@@ -535,7 +562,23 @@ int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
     return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
-                         out_pointers, out_docs, out_class, bin_width, max_value_thr);
+                         out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
+}
+
+int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
+                    uint64_t nreads, uint32_t* out_lengths, uint64_t* out_pointers,
+                    uint32_t* out_docs, spx_class* out_class, uint64_t bin_width,
+                    uint64_t max_value_thr) {
+    return query_host_impl(ix, mode, seqs, offsets, nreads, out_lengths, out_pointers, out_docs, out_class,
+                           bin_width, max_value_thr, 4);
+}
+
+int spx_query_batch16(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
+                      uint64_t nreads, uint16_t* out_lengths, uint64_t* out_pointers,
+                      uint16_t* out_docs, spx_class* out_class, uint64_t bin_width,
+                      uint64_t max_value_thr) {
+    return query_host_impl(ix, mode, seqs, offsets, nreads, out_lengths, out_pointers, out_docs, out_class,
+                           bin_width, max_value_thr, 2);
 }
 
 int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* seqs,

@@ -45,6 +45,7 @@ struct BatchArgs {
     uint64_t max_value_thr;
     WalkCounters* counters;
     uint32_t lanes_per_wave;  // active lanes per wavefront (64 unless the batch is small)
+    uint32_t narrow;          // out_lengths / out_docs point to uint16_t arrays (reads < 65536 characters)
 };
 
 }  // namespace spx

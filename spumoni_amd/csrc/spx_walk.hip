@@ -123,10 +123,36 @@ __device__ __forceinline__ void stage8(uint64_t& lo, uint64_t& hi, uint32_t valu
     }
 }
 
+// The same for 16-bit outputs: the two staging registers ARE the eight u16 values, one
+// 16-byte store per complete group.
+__device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t value, uint16_t* out, uint64_t gi,
+                                        uint32_t xi, uint64_t base, uint32_t m) {
+    const uint32_t slot = (uint32_t)gi & 7;
+    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
+    if (slot & 4)
+        hi |= v;
+    else
+        lo |= v;
+    if (slot == 0 || xi == 0) {
+        const uint64_t g8 = gi & ~7ull;
+        uint16_t* o = out + g8;
+        if (g8 >= base && g8 + 7 < base + m) {
+            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint64_t gt = g8 + t;
+                if (gt >= gi && gt < base + m) o[t] = (uint16_t)((t < 4 ? lo : hi) >> ((t & 3) * 16));
+            }
+        }
+        lo = hi = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
 // ---------------------------------------------------------------------------
-template <int MODE, bool DOC, bool COMPACT>
+template <int MODE, bool DOC, bool COMPACT, bool NARROW>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
     constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
     __shared__ LetterInfo s_let[256];
@@ -336,6 +362,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 rd += nlanes;
                 if (rd >= b.nreads) ph = P_DONE;
             } else {
+                if (NARROW && m >= 65536) n_err++;  // 16-bit outputs cannot hold this read's values
                 x = m;
                 length = 0;
                 sample = ix.init_sample;  // compute_ms_pml.cpp:575
@@ -489,7 +516,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             const uint64_t gi = base + xi;
             if (MODE == SPX_MODE_PML) {
                 // lengths[m-i-1] = length   (:281)
-                if (m < 65536)
+                if (NARROW)
+                    stage8n(ob_lo, ob_hi, length, reinterpret_cast<uint16_t*>(b.out_lengths), gi, xi, base, m);
+                else if (m < 65536)
                     stage8(ob_lo, ob_hi, length, b.out_lengths, gi, xi, base, m);
                 else
                     b.out_lengths[gi] = length;
@@ -515,7 +544,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 }
             }
             if (DOC) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
-                if (m < 65536)
+                if (NARROW)
+                    stage8n(db_lo, db_hi, doc, reinterpret_cast<uint16_t*>(b.out_docs), gi, xi, base, m);
+                else if (m < 65536)
                     stage8(db_lo, db_hi, doc, b.out_docs, gi, xi, base, m);
                 else
                     b.out_docs[gi] = doc;
@@ -644,6 +675,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     const uint64_t base = b.offs[rd];
     const uint64_t m = b.offs[rd + 1] - base;
     uint32_t* out = b.out_lengths + base;
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);  // b.narrow: 16-bit lengths
     const uint8_t* text = ix.text;
     const uint64_t n = ix.n_text;
     const bool want_class = b.out_class != nullptr;
@@ -683,7 +715,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
                 if (adv < 8) break;  // mismatch, or an end reached inside this word
             }
         }
-        if (staged)
+        if (b.narrow)
+            out16[gi] = (uint16_t)l;
+        else if (staged)
             stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, gi, i + 1 == m, base);
         else
             out[i] = (uint32_t)l;
@@ -715,13 +749,13 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     }
 }
 
-template <int MODE, bool DOC, bool COMPACT>
+template <int MODE, bool DOC, bool COMPACT, bool NARROW>
 int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
-        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT>, WALK_TPB, 0));
+        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
     }
     if (ix->num_cus == 0) {
@@ -769,7 +803,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
         grid = (args.nreads + lpw - 1) / lpw;
     }
     if (grid == 0) grid = 1;
-    k_walk_lanes<MODE, DOC, COMPACT><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+    k_walk_lanes<MODE, DOC, COMPACT, NARROW><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
@@ -780,16 +814,31 @@ int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_c
                 hipStream_t stream) {
     (void)total_chars;
     const bool doc = args.out_docs != nullptr;
-    if (ix->view.compact) {
-        if (mode == SPX_MODE_PML) return doc ? launch_lanes<SPX_MODE_PML, true, true>(ix, args, stream)
-                                              : launch_lanes<SPX_MODE_PML, false, true>(ix, args, stream);
-        return doc ? launch_lanes<SPX_MODE_MS, true, true>(ix, args, stream)
-                   : launch_lanes<SPX_MODE_MS, false, true>(ix, args, stream);
+    // pick the instantiation: mode x doc x row encoding x output width
+    const int sel = (mode == SPX_MODE_MS ? 8 : 0) | (doc ? 4 : 0) | (ix->view.compact ? 2 : 0) | (args.narrow ? 1 : 0);
+    switch (sel) {
+#define SPX_CASE(n, M, D, C, N) \
+    case n:                     \
+        return launch_lanes<M, D, C, N>(ix, args, stream);
+        SPX_CASE(0, SPX_MODE_PML, false, false, false)
+        SPX_CASE(1, SPX_MODE_PML, false, false, true)
+        SPX_CASE(2, SPX_MODE_PML, false, true, false)
+        SPX_CASE(3, SPX_MODE_PML, false, true, true)
+        SPX_CASE(4, SPX_MODE_PML, true, false, false)
+        SPX_CASE(5, SPX_MODE_PML, true, false, true)
+        SPX_CASE(6, SPX_MODE_PML, true, true, false)
+        SPX_CASE(7, SPX_MODE_PML, true, true, true)
+        SPX_CASE(8, SPX_MODE_MS, false, false, false)
+        SPX_CASE(9, SPX_MODE_MS, false, false, true)
+        SPX_CASE(10, SPX_MODE_MS, false, true, false)
+        SPX_CASE(11, SPX_MODE_MS, false, true, true)
+        SPX_CASE(12, SPX_MODE_MS, true, false, false)
+        SPX_CASE(13, SPX_MODE_MS, true, false, true)
+        SPX_CASE(14, SPX_MODE_MS, true, true, false)
+        SPX_CASE(15, SPX_MODE_MS, true, true, true)
+#undef SPX_CASE
     }
-    if (mode == SPX_MODE_PML) return doc ? launch_lanes<SPX_MODE_PML, true, false>(ix, args, stream)
-                                          : launch_lanes<SPX_MODE_PML, false, false>(ix, args, stream);
-    return doc ? launch_lanes<SPX_MODE_MS, true, false>(ix, args, stream)
-               : launch_lanes<SPX_MODE_MS, false, false>(ix, args, stream);
+    return SPX_E_ARG;
 }
 
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream) {

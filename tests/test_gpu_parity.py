@@ -32,11 +32,17 @@ def _compare_all(oracle_mod, raw, text, seqs, offs, ix=None):
     assert np.array_equal(got["class"]["above"], a)
     assert np.array_equal(got["class"]["below"], b)
     assert np.array_equal(got["class"]["sum_max"], s)
+    # the 16-bit entry point: same values, half the bytes
+    got16 = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(7, 3), bits=16)
+    assert got16["lengths"].dtype == np.uint16 and np.array_equal(got16["lengths"], want)
+    assert np.array_equal(got16["class"]["above"], a) and np.array_equal(got16["class"]["sum_max"], s)
     if has_docs:
         wl, wd = orc.pml(seqs, offs, want_docs=True)
         got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True)
         assert np.array_equal(got["lengths"], wl)
         assert np.array_equal(got["docs"], wd)
+        got16 = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, bits=16)
+        assert np.array_equal(got16["lengths"], wl) and np.array_equal(got16["docs"], wd)
     # --- MS
     if raw.ssa is not None:
         w = orc.ms(seqs, offs, want_docs=has_docs, text=text)
@@ -45,6 +51,12 @@ def _compare_all(oracle_mod, raw, text, seqs, offs, ix=None):
         assert np.array_equal(got["pointers"], w["pointers"])
         if has_docs:
             assert np.array_equal(got["docs"], w["docs"])
+        got16 = ix.query_host(capi.SPX_MODE_MS, seqs, offs, want_lengths=text is not None, want_docs=has_docs, bits=16)
+        assert np.array_equal(got16["pointers"], w["pointers"])
+        if has_docs:
+            assert np.array_equal(got16["docs"], w["docs"])
+        if text is not None:
+            assert np.array_equal(got16["lengths"], w["lengths"])
         if text is not None:
             assert np.array_equal(got["lengths"], w["lengths"])
             f, a, b, s = oracle_mod.classify(w["lengths"], offs, 5, 4)
@@ -305,3 +317,13 @@ def test_long_runs_and_far_thresholds(gpu, oracle_mod):
         seqs = seqs.cpu().numpy().copy()
         seqs[rng.random(seqs.size) < 0.05] = ord("T")  # jumps to the rare letter from everywhere
         _compare_all(oracle_mod, raw, None, seqs, offs.cpu().numpy())
+
+
+def test_16_bit_outputs_refuse_long_reads(gpu):
+    raw, text = cases.real_case(3, 400, DNA)
+    ix = capi.Index.from_raw(raw, 0)
+    seqs = np.full(70_000, ord("A"), dtype=np.uint8)
+    offs = np.array([0, 70_000])
+    with pytest.raises(capi.SpxError):
+        ix.query_host(capi.SPX_MODE_PML, seqs, offs, bits=16)
+    assert ix.query_host(capi.SPX_MODE_PML, seqs, offs)["lengths"].size == 70_000

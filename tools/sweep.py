@@ -140,3 +140,6 @@ if which in ("realmin",):
         print(f"real minimizer index, {nreads} x {m} bp DNA reads: digest {dg:.2f} ms + walk {wk:.2f} ms "
               f"({total/nreads:.1f} minimizers/read, f_mis {st['jumps']/st['steps']:.3f}, {st['steps']/st['kernel_ms']/1e6:.1f} G steps/s) "
               f"-> {nreads/(dg+wk)/1e3:.1f} M reads/s = {nreads*m/(dg+wk)/1e6:.1f} G bases/s", flush=True)
+    run("real minimizer index, digested reads (walk only)", raw, d_d[:total].clone(), d_do)
+    for w in (12, 16):
+        run("real minimizer index, digested reads (walk only)", raw, d_d[:total].clone(), d_do, waves=w)
