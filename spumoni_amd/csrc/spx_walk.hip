@@ -194,8 +194,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // jump bookkeeping
     uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0, Hland = 0;
     bool quirk = false, peek = false;
-    // character window: 32 bytes starting at byte offset wbase of seqs
-    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, wbase = 0;
+    // character window: the 32 bytes of the read starting at byte offset wbase of seqs, kept in LDS
+    // as [dword j of the window][thread] (conflict-free) -- eight registers and a select chain less
+    // than holding it in VGPRs (90 -> 72 registers, DNA walks +7 %)
+    __shared__ uint32_t s_win[8 * WALK_TPB];
+    uint64_t wbase = 0;
+#define WIN_CHAR(wi) ((s_win[((wi) >> 2) * WALK_TPB + threadIdx.x] >> (((wi)&3) * 8)) & 0xffu)
     // output staging (PML): 8 u16 values of the aligned group of 8 outputs
     uint64_t ob_lo = 0, ob_hi = 0, db_lo = 0, db_hi = 0;
     uint64_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;  // MS pointers of the aligned group of 4
@@ -349,10 +353,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             n_dir++;
             do_decide = true;
         } else if (ph == P_CHARS) {
-            w0 = g0;
-            w1 = g1;
-            w2 = g2;
-            w3 = g3;
+            s_win[0 * WALK_TPB + threadIdx.x] = (uint32_t)g0;
+            s_win[1 * WALK_TPB + threadIdx.x] = (uint32_t)(g0 >> 32);
+            s_win[2 * WALK_TPB + threadIdx.x] = (uint32_t)g1;
+            s_win[3 * WALK_TPB + threadIdx.x] = (uint32_t)(g1 >> 32);
+            s_win[4 * WALK_TPB + threadIdx.x] = (uint32_t)g2;
+            s_win[5 * WALK_TPB + threadIdx.x] = (uint32_t)(g2 >> 32);
+            s_win[6 * WALK_TPB + threadIdx.x] = (uint32_t)g3;
+            s_win[7 * WALK_TPB + threadIdx.x] = (uint32_t)(g3 >> 32);
             do_step = true;  // only entered from a landed state
         } else if (ph == P_READ) {
             base = g0;
@@ -472,8 +480,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 ph = P_CHARS;
             } else {
                 const uint32_t wi = (uint32_t)(g - wbase);
-                const uint64_t wsel = (wi & 16) ? ((wi & 8) ? w3 : w2) : ((wi & 8) ? w1 : w0);
-                c = (uint32_t)(wsel >> ((wi & 7) * 8)) & 0xffu;
+                c = WIN_CHAR(wi);
                 const LetterInfo li = s_let[c];
                 if (li.lid == NO_LETTER) {  // number_of_letter(c) == 0   (:249)
                     length = 0;
@@ -586,8 +593,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     const uint64_t g = base + x - 1;
                     if (g >= wbase && g - wbase < 32) {
                         const uint32_t wi = (uint32_t)(g - wbase);
-                        const uint64_t wsel = (wi & 16) ? ((wi & 8) ? w3 : w2) : ((wi & 8) ? w1 : w0);
-                        const uint32_t cn = (uint32_t)(wsel >> ((wi & 7) * 8)) & 0xffu;
+                        const uint32_t cn = WIN_CHAR(wi);
                         const LetterInfo li = s_let[cn];
                         if (li.lid != NO_LETTER && cn != Hland && k0 < R) {
                             k = k0;
