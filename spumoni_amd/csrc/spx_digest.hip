@@ -45,6 +45,9 @@ struct DigestArgs {
     uint8_t* out;
 };
 
+// "ACGT"[c] without a table: the four letters packed in one constant
+__device__ __forceinline__ uint32_t letter_of(uint32_t c) { return (0x54474341u >> (8 * c)) & 0xffu; }
+
 __device__ __forceinline__ int base_code(uint32_t c) {
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
 }
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(64) k_digest_wave(const DigestArgs a) {
                 } else {
                     const uint32_t code_min = mn ^ a.xm;
                     for (uint32_t j = 0; j < k; ++j)
-                        a.out[ob + e * k + j] = (uint8_t)"ACGT"[(code_min >> (2 * (k - 1 - j))) & 3];
+                        a.out[ob + e * k + j] = (uint8_t)letter_of((code_min >> (2 * (k - 1 - j))) & 3);
                 }
             }
             t_base += __popcll(kv);
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                         } else {
                             const uint32_t code_min = mn ^ a.xm;
                             for (uint32_t t = 0; t < k; ++t)
-                                push_byte((uint32_t)"ACGT"[(code_min >> (2 * (k - 1 - t))) & 3]);
+                                push_byte(letter_of((code_min >> (2 * (k - 1 - t))) & 3));
                         }
                     }
                 }
@@ -308,9 +311,17 @@ __global__ void __launch_bounds__(64) k_digest_unstash(const DigestArgs a, const
                                 stage[r - w0] = (uint8_t)byte;
                             } else {
                                 const uint32_t code = byte ^ a.xm;
-                                for (uint32_t i = 0; i < k; ++i)
-                                    if (r + i >= w0 && r + i < w1)
-                                        stage[r + i - w0] = (uint8_t)"ACGT"[(code >> (2 * (k - 1 - i))) & 3];
+                                if (k == 4 && r >= w0 && r + 4 <= w1) {  // the usual case: four letters, one write
+                                    const uint32_t four = letter_of((code >> 6) & 3) |
+                                                          (letter_of((code >> 4) & 3) << 8) |
+                                                          (letter_of((code >> 2) & 3) << 16) |
+                                                          (letter_of(code & 3) << 24);
+                                    __builtin_memcpy(stage + (r - w0), &four, 4);
+                                } else {
+                                    for (uint32_t i = 0; i < k; ++i)
+                                        if (r + i >= w0 && r + i < w1)
+                                            stage[r + i - w0] = (uint8_t)letter_of((code >> (2 * (k - 1 - i))) & 3);
+                                }
                             }
                         }
                     }
