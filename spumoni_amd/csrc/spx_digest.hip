@@ -144,8 +144,11 @@ __device__ __forceinline__ uint32_t byte_min8(uint64_t w) {
     return min(m & 0xffffu, m >> 16);
 }
 
-template <int PASS, int KIND>
+// FAST8: the window holds eight k-mers (the default k = 4, w = 11): steps whose four characters
+// are all ACGT and whose window is full take a path that updates the window four k-mers at a time
+template <int KIND, bool FAST8>
 __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
+    constexpr int PASS = 2;  // count + park the minimizer bytes at the read's input offset (see below)
     __shared__ uint4 tile16[TILE / 16 + 1];  // + slack for the last 4-byte read of a read
     __shared__ uint8_t lut[256];
     const uint8_t* const tile = reinterpret_cast<const uint8_t*>(tile16);
@@ -165,7 +168,6 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
         // go: counts, and the minimizer bytes parked at the read's INPUT offset in a scratch buffer
         // (k_digest_unstash moves them once the offsets are known) -- the reads are digested once
         uint64_t ob = 0;
-        if (PASS == 1 && live) ob = a.out_offs[rd];
         if (PASS == 2) ob = rbeg;
         // the lane's walk state
         uint32_t filled = 0, kmer = 0, cnt = 0, last = 0, acc = 0, nacc = 0;
@@ -184,6 +186,26 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                 }
                 acc = 0;
                 nacc = 0;
+            }
+        };
+        auto push_bytes = [&](uint32_t q, uint32_t nq) {  // nq <= 4 bytes of the digest, packed low first
+            const uint64_t addr = ob + e;
+            const uint32_t fill = (uint32_t)(addr & 3);
+            const uint64_t comb = (uint64_t)acc | ((uint64_t)q << (8 * fill));
+            e += nq;
+            if (fill + nq >= 4) {  // the aligned dword that holds addr is complete
+                const uint32_t lo = (uint32_t)comb;
+                uint8_t* const d = a.out + (addr - fill);
+                if (nacc == fill) {
+                    *reinterpret_cast<uint32_t*>(d) = lo;
+                } else {  // its first bytes belong to the previous read
+                    for (uint32_t j = fill - nacc; j < 4; ++j) d[j] = (uint8_t)(lo >> (8 * j));
+                }
+                acc = (uint32_t)(comb >> 32);
+                nacc = fill + nq - 4;
+            } else {
+                acc = (uint32_t)comb;
+                nacc += nq;
             }
         };
         for (uint64_t t0 = g0 & ~15ull; t0 < g1; t0 += TILE) {
@@ -211,6 +233,61 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                 // tile array is over-allocated so that the read stays inside LDS)
                 uint32_t w4 = 0;
                 if (s < mine) __builtin_memcpy(&w4, tile + off + s, 4);
+                if (FAST8) {
+                    bool regular = s + 4 <= mine && filled == k && cnt == 8 && have;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t d = ((w4 >> (8 * j)) & 0xffu) - 'A';
+                        regular = regular && d < 20 && ((0x80045u >> d) & 1);  // A C G T
+                    }
+                    if (regular) {
+                        // the four k-mers ending at these characters, their keys
+                        const uint32_t t4 = ((w4 >> 1) ^ (w4 >> 2)) & 0x03030303u;  // codes, first character low
+                        const uint32_t c8 = (t4 * 0x40100401u) >> 24;               // c0<<6 | c1<<4 | c2<<2 | c3
+                        const uint32_t x = (kmer << 8) | c8;
+                        const uint32_t km0 = (x >> 6) & kmask, km1 = (x >> 4) & kmask, km2 = (x >> 2) & kmask;
+                        kmer = x & kmask;
+                        uint32_t q0, q1, q2, q3;
+                        if (KIND == SPX_DIGEST_PROMOTED) {
+                            q0 = lut[km0];
+                            q1 = lut[km1];
+                            q2 = lut[km2];
+                            q3 = lut[kmer];
+                        } else {
+                            q0 = km0 ^ a.xm;
+                            q1 = km1 ^ a.xm;
+                            q2 = km2 ^ a.xm;
+                            q3 = kmer ^ a.xm;
+                        }
+                        // minima of the four windows: old keys b0 (newest) .. b6, new keys q0 .. q3
+                        const uint32_t wl = (uint32_t)win, wh = (uint32_t)(win >> 32);
+                        const uint32_t p1 = min(wl & 0xffu, (wl >> 8) & 0xffu);
+                        const uint32_t p2 = min(p1, (wl >> 16) & 0xffu);
+                        const uint32_t p3 = min(p2, wl >> 24);
+                        const uint32_t p4 = min(p3, wh & 0xffu);
+                        const uint32_t p5 = min(p4, (wh >> 8) & 0xffu);
+                        const uint32_t p6 = min(p5, (wh >> 16) & 0xffu);
+                        const uint32_t n1 = min(q0, q1), n2 = min(n1, q2), n3 = min(n2, q3);
+                        const uint32_t m0 = min(q0, p6), m1 = min(n1, p5), m2 = min(n2, p4), m3 = min(n3, p3);
+                        win = (win << 32) | ((uint64_t)q0 << 24) | (q1 << 16) | (q2 << 8) | q3;
+                        // what the caller's lambda keeps (:305 / :333), in order
+                        const bool e0 = m0 != last, e1 = m1 != m0, e2 = m2 != m1, e3 = m3 != m2;
+                        last = m3;
+                        const uint32_t v0 = (KIND == SPX_DIGEST_PROMOTED && m0 <= 2) ? m0 + 3 : m0;
+                        const uint32_t v1 = (KIND == SPX_DIGEST_PROMOTED && m1 <= 2) ? m1 + 3 : m1;
+                        const uint32_t v2 = (KIND == SPX_DIGEST_PROMOTED && m2 <= 2) ? m2 + 3 : m2;
+                        const uint32_t v3 = (KIND == SPX_DIGEST_PROMOTED && m3 <= 2) ? m3 + 3 : m3;
+                        uint32_t q = e0 ? v0 : 0, nq = e0 ? 1 : 0;
+                        q |= e1 ? v1 << (8 * nq) : 0;
+                        nq += e1 ? 1 : 0;
+                        q |= e2 ? v2 << (8 * nq) : 0;
+                        nq += e2 ? 1 : 0;
+                        q |= e3 ? v3 << (8 * nq) : 0;
+                        nq += e3 ? 1 : 0;
+                        if (nq) push_bytes(q, nq);
+                        continue;
+                    }
+                }
                 uint32_t kmers[4], keys[4];
                 bool act[4], has[4];
 #pragma unroll
@@ -428,9 +505,11 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
         a.out = stash;
         if (kind == SPX_DIGEST_PROMOTED)
-            k_digest_lanes<2, SPX_DIGEST_PROMOTED><<<grid, 64, 0, st>>>(a);
+            a.wsz == 8 ? k_digest_lanes<SPX_DIGEST_PROMOTED, true><<<grid, 64, 0, st>>>(a)
+                       : k_digest_lanes<SPX_DIGEST_PROMOTED, false><<<grid, 64, 0, st>>>(a);
         else
-            k_digest_lanes<2, SPX_DIGEST_DNA><<<grid, 64, 0, st>>>(a);
+            a.wsz == 8 ? k_digest_lanes<SPX_DIGEST_DNA, true><<<grid, 64, 0, st>>>(a)
+                       : k_digest_lanes<SPX_DIGEST_DNA, false><<<grid, 64, 0, st>>>(a);
         SPX_HIP(hipGetLastError());
         int rc = scan_counts();
         if (rc != SPX_OK) return rc;
