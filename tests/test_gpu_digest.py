@@ -36,7 +36,7 @@ def _ragged_dna(rng, nreads, maxlen, p_n):
 
 
 @pytest.mark.parametrize("kind", [capi.SPX_DIGEST_PROMOTED, capi.SPX_DIGEST_DNA])
-@pytest.mark.parametrize("k,w", [(4, 11), (4, 4), (1, 1), (2, 3), (3, 20), (4, 100), (1, 64), (4, 131)])
+@pytest.mark.parametrize("k,w", [(4, 11), (3, 10), (2, 9), (1, 8), (4, 4), (1, 1), (2, 3), (3, 20), (4, 100), (1, 64), (4, 131)])
 def test_digest_matches_oracle(gpu, oracle_mod, small_index, kind, k, w):
     ix = small_index[2]
     rng = np.random.default_rng(100 * k + w + kind)
