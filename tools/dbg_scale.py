@@ -1,3 +1,7 @@
+"""Debug aid: compare the HIP walk with the oracle on a statistical index of r runs for forced fat block sizes.
+
+    python tools/dbg_scale.py <runs> auto 0 1 2     (through gpurun)
+"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from spumoni_amd import capi, synth
