@@ -143,3 +143,9 @@ if which in ("realmin",):
     run("real minimizer index, digested reads (walk only)", raw, d_d[:total].clone(), d_do)
     for w in (12, 16):
         run("real minimizer index, digested reads (walk only)", raw, d_d[:total].clone(), d_do, waves=w)
+if which in ("longlpw",):
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    for n in (6_250, 50_000):
+        seqs, offs = synth.simulate_reads(raw, n, 2200, seed=17)
+        for lpw in (0, 1, 2, 4, 8):
+            run(f"C5 {n} x 2200", raw, seqs, offs, lpw=lpw, reps=2)
