@@ -400,12 +400,12 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     // outright when no c-run lies between its block's start and the walk's run, so smaller
     // blocks mean fewer Q / dirrow gathers (measured on C3, same box: 787 / 804 / 867 / 912 M
     // reads/s at 128 / 64 / 32 / 16 runs per block, for 29 / 45 / 77 / 140 GiB of index).  The
-    // densest table is taken that keeps the whole flat index within the budget: 60 % of the
+    // densest table is taken that keeps the whole flat index within the budget: 66 % of the
     // memory free on the device right now (SPX_INDEX_BUDGET_GB overrides), never coarser than
     // nletters / 3 runs per block (~96 B per run).
     size_t mem_free = 0, mem_total = 0;
     SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
-    double budget = 0.6 * (double)mem_free;
+    double budget = 0.66 * (double)mem_free;
     if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     const bool has_ms = d_ssa && d_esa;
     const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
