@@ -170,8 +170,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
     // predecessor landing = LF(S[k]) - 1 = LF of the last character of the previous run in
     // directory order
     const bool psame = soff > 0;  // for i == 0 (lf == 0) there is no predecessor: never taken
-    const uint32_t hs = Hrun[dst], hp = dst > 0 ? Hrun[dst - 1] : 0;
-    dirrows[i] = pack_jumprow(k, (uint32_t)trun, toff, (uint32_t)dst, soff, psame, hs, hp, (uint32_t)i);
+    dirrows[i] = pack_jumprow(k, (uint32_t)trun, toff, (uint32_t)dst, soff, psame, Hrun[dst], (uint32_t)i);
     if (dirdocs) {
         uint64_t d0 = ds[k], d1 = de[k], dp = i > 0 ? de[Qall[i - 1]] : 0;
         if (d0 > 0xffff || d1 > 0xffff) atomicAdd(err, 1ull);
@@ -183,7 +182,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
         }
     }
     if (i + 1 == r) {  // sentinel jump row r: LF image n, predecessor = position n-1
-        JumpRow sd = pack_jumprow((uint32_t)r, 0, 0, (uint32_t)r, 0, false, 0, Hrun[r - 1], (uint32_t)r);
+        JumpRow sd = pack_jumprow((uint32_t)r, 0, 0, (uint32_t)r, 0, false, 0, (uint32_t)r);
         for (int t = 0; t < 4; ++t) dirrows[r + t] = sd;
     }
 }

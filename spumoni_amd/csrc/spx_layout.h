@@ -21,7 +21,7 @@
 //        pLF      where LF(start of q) - 1 lands    (pos <  THR: predecessor; this
 //                 is LF of the LAST character of the previous c-run, because LF
 //                 images of consecutive same-letter runs are adjacent): one bit
-//        Hs, Hp   heads of the runs the two landings are in
+//        Hs       head of the run the successor landing is in
 //        j        position of q in the (letter, run index) order
 //      dirrows[j]            one JumpRow per run, in (letter, run index) order
 //      fat[letter][k >> s]   a 16-byte digest (FatRow) of the JumpRow of the first c-run at
@@ -103,25 +103,25 @@ struct alignas(32) JumpRow {
     uint64_t d0;  // q[32] | THRrun[32] << 32
     uint64_t d1;  // THRoff[40] | sLFrun[0:24] << 40
     uint64_t d2;  // sLFoff[40] | sLFrun[24:32] << 40 | psame << 48 | Hs[8] << 49
-    uint64_t d3;  // j[32] | Hp[8] << 32
+    uint64_t d3;  // j[32]
 };
 
 // psame: the predecessor landing is in the same run as the successor landing (then it is
 // (sLFrun, sLFoff-1)); otherwise it is the LAST position of run sLFrun-1, which the landing
 // gather resolves (offset sentinel OFF_END).
-// Hs / Hp: heads of run sLFrun / sLFrun-1.  With them the walk knows the head of the run a
-// jump lands in before touching that run's row: if the next character differs from it, the
-// next step is another jump and the landing row is never fetched (a mismatch-heavy read then
-// costs ONE gather per character instead of two).
+// Hs: head of run sLFrun.  With it the walk knows the head of the run a jump lands in before
+// touching that run's row: if the next character differs from it, the next step is another jump
+// and the landing row is never fetched (a mismatch-heavy read then costs ONE gather per character
+// instead of two).  (A predecessor landing in run sLFrun-1 always fetches that run's row.)
 constexpr uint64_t OFF_END = ~0ull;
 SPX_HD JumpRow pack_jumprow(uint32_t q, uint32_t THRrun, uint64_t THRoff, uint32_t sLFrun,
-                            uint64_t sLFoff, bool psame, uint32_t Hs, uint32_t Hp, uint32_t j) {
+                            uint64_t sLFoff, bool psame, uint32_t Hs, uint32_t j) {
     JumpRow d;
     d.d0 = (uint64_t)q | ((uint64_t)THRrun << 32);
     d.d1 = (THRoff & MASK40) | ((uint64_t)(sLFrun & 0xffffff) << 40);
     d.d2 = (sLFoff & MASK40) | ((uint64_t)(sLFrun >> 24) << 40) | ((uint64_t)(psame ? 1 : 0) << 48) |
            ((uint64_t)(Hs & 0xff) << 49);
-    d.d3 = (uint64_t)j | ((uint64_t)(Hp & 0xff) << 32);
+    d.d3 = (uint64_t)j;
     return d;
 }
 SPX_HD uint32_t jr_q(const JumpRow& d) { return (uint32_t)d.d0; }
@@ -133,7 +133,6 @@ SPX_HD uint32_t jr_sLFrun(const JumpRow& d) {
 SPX_HD uint64_t jr_sLFoff(const JumpRow& d) { return d.d2 & MASK40; }
 SPX_HD bool jr_psame(const JumpRow& d) { return (d.d2 >> 48) & 1; }
 SPX_HD uint32_t jr_Hs(const JumpRow& d) { return (uint32_t)(d.d2 >> 49) & 0xff; }
-SPX_HD uint32_t jr_Hp(const JumpRow& d) { return (uint32_t)(d.d3 >> 32) & 0xff; }
 SPX_HD uint32_t jr_j(const JumpRow& d) { return (uint32_t)d.d3; }
 
 // What a fat slot holds: the JumpRow of the first c-run at or after its block, squeezed into ONE
