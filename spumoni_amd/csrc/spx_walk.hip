@@ -667,12 +667,13 @@ __device__ __forceinline__ void stage8_up(uint64_t& lo, uint64_t& hi, uint32_t v
     }
 }
 
+// eight bytes at any byte address: ONE global_load_dwordx2 (gfx950 under HSA takes unaligned
+// vector loads; two aligned loads + a funnel shift doubled the kernel's lane loads, which is
+// what it is bound by)
 __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* base, uint64_t idx) {
-    const uint64_t* w = reinterpret_cast<const uint64_t*>(base) + (idx >> 3);
-    const uint32_t sh = (uint32_t)(idx & 7) * 8;
-    const uint64_t lo = w[0];
-    if (sh == 0) return lo;
-    return (lo >> sh) | (w[1] << (64 - sh));
+    uint64_t v;
+    __builtin_memcpy(&v, base + idx, 8);
+    return v;
 }
 
 __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const BatchArgs b) {
