@@ -775,10 +775,11 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     // (With 32-byte fat rows -- two 16-byte lane loads per jump -- 12 was the optimum, 971 / 935 /
     // 914: the kernel sits at the chip's rate of ~80 G 16-byte lane loads per second, and more
     // chains only lengthened the queue.)
-    // Match-heavy walks over small alphabets do best at 16 (DNA: 38.7 / 41.0 / 39.7 G steps/s), the
-    // variants that also fetch samples / document ids per jump at 12 (MS+doc 26.3 / 24.5 / 24.1).
+    // Match-heavy walks over small alphabets do best at 16 (DNA: 38.7 / 41.0 / 39.7 G steps/s); the
+    // variants that also fetch the aux record per jump like 20 too (MS+doc 27.6 / 28.0 / 28.4,
+    // PML+doc 30.3 / 32.2 / 33.0).
     int occ = ix->occ_blocks[slot];
-    const int auto_waves = (MODE == SPX_MODE_MS || DOC) ? 12 : (ix->view.nletters > 16 ? 20 : 16);
+    const int auto_waves = ix->view.nletters > 16 ? 20 : 16;
     const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : auto_waves;
     int want = target_waves / (WALK_TPB / 64);
     if (want < 1) want = 1;
