@@ -185,6 +185,7 @@ spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const
     spx_index* ix = new spx_index();
     ix->device = device;
     default_charhash(ix->charhash);
+    if (const char* e = getenv("SPX_WAVES_PER_CU")) ix->waves_per_cu = atoi(e);  // experiment knob
     if (from_runs_impl(ix, heads, lens, thr, r, ssa, esa, doc_start, doc_end, where) != SPX_OK) {
         spx_index_free(ix);
         return nullptr;
