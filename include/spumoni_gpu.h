@@ -115,7 +115,9 @@ int spx_index_set_text(spx_index *ix, const uint8_t *text, uint64_t n_text, int 
  *   out_docs      document ids (index must have been built with doc arrays)
  *   out_class     nreads entries, bin-max classifier over out_lengths' values
  *                 (bin_width in [1, ..]; ignored when out_class is NULL)
- * Host-buffer form: copies in, runs, copies out, returns when done.          */
+ * Host-buffer form: copies in, runs, copies out, returns when done (large
+ * batches as a pipeline of chunks, so that the copies overlap the kernels; the
+ * kernel time spx_last_walk_stats reports then spans that pipeline).           */
 int spx_query_batch(spx_index *ix, int mode, const uint8_t *seqs, const uint64_t *offsets,
                     uint64_t nreads, uint32_t *out_lengths, uint64_t *out_pointers,
                     uint32_t *out_docs, spx_class *out_class, uint64_t bin_width,

@@ -110,6 +110,12 @@ void spx_index_free(spx_index* ix) {
     if (ix->letters) (void)hipFree(ix->letters);
     if (ix->text) (void)hipFree(ix->text);
     if (ix->counters) (void)hipFree(ix->counters);
+    for (auto& st : ix->pipe_s)
+        if (st) (void)hipStreamDestroy(st);
+    for (int c = 0; c < spx_index::PIPE_CHUNKS; ++c) {
+        if (ix->pipe_in[c]) (void)hipEventDestroy(ix->pipe_in[c]);
+        if (ix->pipe_k[c]) (void)hipEventDestroy(ix->pipe_k[c]);
+    }
     for (auto& sc : ix->scratch)
         if (sc.p) (void)hipFree(sc.p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -539,6 +545,93 @@ static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const ui
     return SPX_OK;
 }
 
+// Large host batches: chunks of reads go through copy-in / walk / copy-out on three streams, so the
+// PCIe transfers of one chunk overlap the kernel of another.  Offsets are absolute, so every chunk
+// is launched on the same device buffers with the offsets pointer advanced.  Caller holds host_mu.
+static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets, uint64_t nreads,
+                         uint8_t* d_seq, uint64_t* d_off, uint64_t padded, void* out_lengths, uint64_t* out_pointers,
+                         void* out_docs, spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr,
+                         size_t width) {
+    const uint64_t total = offsets[nreads];
+    void *dlen = nullptr, *dptr = nullptr, *ddoc = nullptr, *dcls = nullptr;
+    int rc;
+    if (out_lengths && (rc = ensure_scratch(ix, 2, (total + 1) * 4, &dlen)) != SPX_OK) return rc;
+    if (out_pointers && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &dptr)) != SPX_OK) return rc;
+    if (out_docs && (rc = ensure_scratch(ix, 4, (total + 1) * 4, &ddoc)) != SPX_OK) return rc;
+    if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
+    std::lock_guard<std::mutex> g(ix->mu);
+    constexpr int NCH = spx_index::PIPE_CHUNKS;
+    if (!ix->pipe_s[0]) {
+        for (auto& st : ix->pipe_s) SPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int c = 0; c < NCH; ++c) {
+            SPX_HIP(hipEventCreateWithFlags(&ix->pipe_in[c], hipEventDisableTiming));
+            SPX_HIP(hipEventCreateWithFlags(&ix->pipe_k[c], hipEventDisableTiming));
+        }
+    }
+    hipStream_t s_in = ix->pipe_s[0], s_k = ix->pipe_s[1], s_out = ix->pipe_s[2];
+    if (ix->have_timing && ix->last_stream != s_k) SPX_HIP(hipStreamWaitEvent(s_k, ix->ev_done, 0));
+    SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), s_k));
+    SPX_HIP(hipEventRecord(ix->ev0, s_k));
+    // offsets and the read-ahead padding first, on the copy-in stream: every chunk's event covers them
+    SPX_HIP(hipMemcpyAsync(d_off, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, s_in));
+    SPX_HIP(hipMemsetAsync(d_seq + total, 0, padded - total, s_in));
+    for (int c = 0; c < NCH; ++c) {
+        const uint64_t q0 = nreads * c / NCH, q1 = nreads * (c + 1) / NCH;
+        if (q1 == q0) continue;
+        const uint64_t a = offsets[q0], b = offsets[q1];
+        SPX_HIP(hipMemcpyAsync(d_seq + a, seqs + a, b - a, hipMemcpyHostToDevice, s_in));
+        SPX_HIP(hipEventRecord(ix->pipe_in[c], s_in));
+        SPX_HIP(hipStreamWaitEvent(s_k, ix->pipe_in[c], 0));
+        BatchArgs args;
+        args.seqs = d_seq;
+        args.offs = d_off + q0;
+        args.nreads = q1 - q0;
+        args.total_chars = b - a;
+        args.out_lengths = (uint32_t*)dlen;
+        args.out_pointers = (uint64_t*)dptr;
+        args.out_docs = (uint32_t*)ddoc;
+        args.out_class = (mode == SPX_MODE_PML && dcls) ? (spx_class*)dcls + q0 : nullptr;
+        args.bin_width = bin_width;
+        args.bin_magic = bin_width > 1 ? (uint64_t)(~0ull / bin_width) + 1 : 0;
+        args.max_value_thr = max_value_thr;
+        args.counters = ix->counters;
+        args.narrow = width == 2 ? 1 : 0;
+        if ((rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK) return rc;
+        if (mode == SPX_MODE_MS && dlen) {
+            args.out_class = dcls ? (spx_class*)dcls + q0 : nullptr;
+            if ((rc = launch_ms_extend(ix, args, s_k)) != SPX_OK) return rc;
+        }
+        SPX_HIP(hipEventRecord(ix->pipe_k[c], s_k));
+        SPX_HIP(hipStreamWaitEvent(s_out, ix->pipe_k[c], 0));
+        if (out_lengths)
+            SPX_HIP(hipMemcpyAsync((char*)out_lengths + a * width, (char*)dlen + a * width, (b - a) * width,
+                                   hipMemcpyDeviceToHost, s_out));
+        if (out_pointers)
+            SPX_HIP(hipMemcpyAsync(out_pointers + a, (uint64_t*)dptr + a, (b - a) * 8, hipMemcpyDeviceToHost, s_out));
+        if (out_docs)
+            SPX_HIP(hipMemcpyAsync((char*)out_docs + a * width, (char*)ddoc + a * width, (b - a) * width,
+                                   hipMemcpyDeviceToHost, s_out));
+        if (out_class)
+            SPX_HIP(hipMemcpyAsync(out_class + q0, (spx_class*)dcls + q0, (q1 - q0) * sizeof(spx_class),
+                                   hipMemcpyDeviceToHost, s_out));
+    }
+    SPX_HIP(hipEventRecord(ix->ev1, s_k));
+    SPX_HIP(hipEventRecord(ix->ev_done, s_k));
+    ix->have_timing = true;
+    ix->last_stream = s_k;
+    SPX_HIP(hipStreamSynchronize(s_out));
+    SPX_HIP(hipStreamSynchronize(s_k));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    if (wc.error) {
+        set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
+                  "thresholds are inconsistent with the BWT%s)", wc.error,
+                  width == 2 ? "; or a read of 65536 characters or more with 16-bit outputs" : "");
+        return SPX_E_FORMAT;
+    }
+    return SPX_OK;
+}
+
 static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets, uint64_t nreads,
                            void* out_lengths, uint64_t* out_pointers, void* out_docs, spx_class* out_class,
                            uint64_t bin_width, uint64_t max_value_thr, size_t width) {
@@ -558,10 +651,13 @@ static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const u
     void *dseq = nullptr, *doff = nullptr;
     const uint64_t padded = ((total + 3) / 4) * 4 + 32;
     if ((rc = ensure_scratch(ix, 0, padded, &dseq)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemset((char*)dseq + total, 0, padded - total));
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
+    if (nreads >= (uint64_t)spx_index::PIPE_CHUNKS * 32768 && total >= (64u << 20))
+        return run_pipelined(ix, mode, seqs, offsets, nreads, (uint8_t*)dseq, (uint64_t*)doff, padded, out_lengths,
+                             out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
     SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemset((char*)dseq + total, 0, padded - total));
+    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
     return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
                          out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
 }

@@ -77,6 +77,11 @@ struct spx_index {
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
     int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read
     uint8_t charhash[4] = {0, 0, 0, 0};  // -m digestion: 8-bit character hashes of A, C, G, T
+    // host-buffer queries of large batches run as a pipeline over chunks of reads: copy in,
+    // walk, copy out on three streams (created on first use)
+    static constexpr int PIPE_CHUNKS = 8;
+    hipStream_t pipe_s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t pipe_in[PIPE_CHUNKS] = {}, pipe_k[PIPE_CHUNKS] = {};
     std::mutex mu;       // device-buffer queries / options
     std::mutex host_mu;  // host-buffer queries (own the scratch below)
     struct Scratch {

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from spumoni_amd import capi, synth
+from tests import cases
 
 pytestmark = pytest.mark.gpu
 
@@ -100,3 +101,47 @@ def test_config5_long_reads(oracle_mod):
     got, _ = _pml_dev(ix, long_seqs, long_offs)
     want = orc.pml(long_seqs.cpu().numpy(), long_offs.cpu().numpy())
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want)
+
+
+def test_host_entry_points_pipeline_large_batches(oracle_mod):
+    """spx_query_batch / spx_query_batch16 run batches of >= 2^18 reads and >= 64 MB as a pipeline of
+    chunks over three streams: same results as the device entry point (PML + doc + classes, MS
+    pointers / lengths), and as the oracle on a sample."""
+    rng = np.random.default_rng(4)
+    raw, text = cases.real_case(9, 200_000, list(b"ACGT"), ndocs=5)
+    ix = capi.Index.from_raw(raw, 0)
+    nreads, m = 640_000, 130  # ragged below
+    lens = rng.integers(90, m + 1, size=nreads)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    starts = rng.integers(0, text.size - m, size=nreads)
+    seqs = np.empty(int(offs[-1]), dtype=np.uint8)
+    big = text[(starts[:, None] + np.arange(m)[None, :])]
+    mask = np.arange(m)[None, :] < lens[:, None]
+    seqs[:] = big[mask]
+    flip = rng.random(seqs.size) < 0.02
+    seqs[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(flip.sum()))]
+    assert seqs.size >= (64 << 20)
+    d_seqs, d_offs = torch.from_numpy(seqs).cuda(), torch.from_numpy(offs).cuda()
+    want_l, want_c = _pml_dev(ix, d_seqs, d_offs, classify=(50, 4))
+    want_l = want_l.cpu().numpy().view(np.uint32)
+    cls32 = want_c.view(torch.int32).view(nreads, 4).cpu().numpy()
+    for bits in (32, 16):
+        got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, classify=(50, 4), bits=bits)
+        assert np.array_equal(got["lengths"], want_l)
+        assert np.array_equal(got["class"]["above"], cls32[:, 2].view(np.uint32))
+        assert np.array_equal(got["class"]["below"], cls32[:, 3].view(np.uint32))
+        ms = ix.query_host(capi.SPX_MODE_MS, seqs, offs, want_docs=True, bits=bits)
+        if bits == 32:
+            ref_ms, ref_docs = ms, got["docs"]
+        else:
+            assert np.array_equal(ms["pointers"], ref_ms["pointers"])
+            assert np.array_equal(ms["lengths"], ref_ms["lengths"])
+            assert np.array_equal(ms["docs"], ref_ms["docs"]) and np.array_equal(got["docs"], ref_docs)
+    ns = 3000
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    wl, wd = orc.pml(seqs[: offs[ns]], offs[: ns + 1], want_docs=True)
+    assert np.array_equal(want_l[: offs[ns]], wl) and np.array_equal(ref_docs[: offs[ns]], wd)
+    w = orc.ms(seqs[: offs[ns]], offs[: ns + 1], want_docs=True, text=text)
+    assert np.array_equal(ref_ms["pointers"][: offs[ns]], w["pointers"])
+    assert np.array_equal(ref_ms["lengths"][: offs[ns]], w["lengths"])
+    assert np.array_equal(ref_ms["docs"][: offs[ns]], w["docs"])
