@@ -14,7 +14,7 @@ raw = synth.index_from_text(torch.from_numpy(text).cuda(), with_samples=False).c
 open(f"{d}/ref.fa", "w").write(">x\n")
 raw.write_raw_files(f"{d}/ref.fa")
 write_null_db(f"{d}/ref.fa.pmlnulldb", 3.0, [1, 2, 3, 3, 3, 3, 3])
-nreads, m = 1_000_000, 200
+nreads, m = int(os.environ.get("E2E_READS", "1000000")), 200
 seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
 t0 = time.time()
 with open(f"{d}/reads.fa", "wb") as f:
