@@ -101,8 +101,34 @@ int spx_index_stats(const spx_index *ix, uint64_t *n, uint64_t *r);
 /* bytes of HBM the flat layout occupies                                       */
 int spx_index_device_bytes(const spx_index *ix, uint64_t *bytes);
 /* Text for the MS length extension (ms_t's `ra.charAt`, compute_ms_pml.cpp:805):
- * the plain text replaces the SLP random-access structure.  where: 0 host, 1 device. */
+ * the plain text replaces the SLP random-access structure (ms_t loads the SLP of
+ * the SAME text the BWT was built from, :769-774).  where: 0 host, 1 device.
+ * The text is checked against the index before it is accepted: it must have
+ * n - 1 characters (the BWT has one position per character plus the
+ * terminator), and -- index with SA samples -- text[samples_start[k]] must be the
+ * head of run k for every run (the BWT character is the text character in front
+ * of the suffix).  A text that fails is refused with SPX_E_FORMAT: wrong MS
+ * lengths would otherwise come out silently.  where | SPX_TEXT_UNCHECKED skips
+ * the check (synthetic indexes that are not the BWT of any text).              */
+#define SPX_TEXT_UNCHECKED 2
 int spx_index_set_text(spx_index *ix, const uint8_t *text, uint64_t n_text, int where);
+
+/* ---- flat-layout cache and replication -------------------------------------
+ * pml_t / ms_t deserialise their index on every run (compute_ms_pml.cpp:700-721,
+ * 755-786, the timed "loading the index" step).  Here the raw run files are
+ * flattened on the device (seconds at 10^9 runs); spx_index_save writes the
+ * flat arrays as they are (<path>, by convention <ref>.<mode>.spx), and
+ * spx_index_load_flat brings them back with nothing but file reads and
+ * host-to-device copies.  A cache written by another layout version
+ * (spx_version()) is refused.  spx_index_clone copies an index to another
+ * device (peer-to-peer over xGMI where the devices reach each other): flatten
+ * once, replicate N-1 times ("index replicated in each GPU's HBM"). */
+const char *spx_version(void);
+int spx_index_save(spx_index *ix, const char *path);
+spx_index *spx_index_load_flat(const char *path, int device);
+spx_index *spx_index_clone(spx_index *src, int device);
+/* one-line JSON description of the layout (sizes, fat-table density, version) */
+int spx_index_describe(const spx_index *ix, char *buf, size_t cap);
 
 /* ---- queries -------------------------------------------------------------
  * Batch form of matching_statistics.  seqs = concatenated reads, already
@@ -173,7 +199,9 @@ void spx_host_free(void *p);
 uint64_t spx_digest_capacity(int kind, uint32_t k, uint64_t total_chars);
 /* Device form: digested reads, concatenated, into d_out_seqs (16-byte aligned if
  * it is to be queried), their nreads+1 offsets into d_out_offsets; enqueued on
- * `stream`, returns without synchronising.  d_out_seqs / d_out_offsets can be
+ * `stream`, returns without synchronising.  d_seqs must be 16-byte aligned and
+ * readable for round_up(total_chars, 16) + 16 bytes (the kernels stage the reads
+ * with aligned 16-byte loads): SPX_E_ARG otherwise.  d_out_seqs / d_out_offsets can be
  * handed to spx_query_batch_device as they are (total = d_out_offsets[nreads]). */
 int spx_digest_batch_device(spx_index *ix, int kind, uint32_t k, uint32_t w, const uint8_t *d_seqs,
                             const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
@@ -197,7 +225,7 @@ int spx_digest_query_batch(spx_index *ix, int mode, int kind, uint32_t k, uint32
                            uint64_t bin_width, uint64_t max_value_thr);
 
 /* ---- tuning knobs (optional) --------------------------------------------- */
-/* keys: "waves_per_cu" (occupancy target, default 12), "lanes_per_wave" (reads per
+/* keys: "waves_per_cu" (occupancy target; default 20, 16 for alphabets of <= 16 letters), "lanes_per_wave" (reads per
  * wavefront, 0 = automatic; 1 = the one-wavefront-per-read mapping of SURVEY 7.1,
  * kept as a measurable experiment -- see DESIGN.md 4.1)                        */
 /* "minimizer_charhash": see the digestion section above                        */

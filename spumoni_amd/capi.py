@@ -42,7 +42,13 @@ EXPORTS = [
     "spx_digest_batch",
     "spx_digest_batch_device",
     "spx_digest_query_batch",
+    "spx_version",
+    "spx_index_save",
+    "spx_index_load_flat",
+    "spx_index_clone",
+    "spx_index_describe",
 ]
+SPX_TEXT_UNCHECKED = 2
 
 SPX_DIGEST_PROMOTED, SPX_DIGEST_DNA = 1, 2
 
@@ -116,8 +122,20 @@ def lib() -> C.CDLL:
         L.spx_digest_batch.argtypes = [vp, i32, u32, u32, vp, vp, u64, vp, u64, vp]
         L.spx_digest_batch_device.argtypes = [vp, i32, u32, u32, vp, vp, u64, u64, vp, u64, vp, vp]
         L.spx_digest_query_batch.argtypes = [vp, i32, i32, u32, u32, vp, vp, u64, vp, u64, vp, vp, vp, vp, u64, u64]
+        L.spx_version.restype = C.c_char_p
+        L.spx_index_save.argtypes = [vp, C.c_char_p]
+        L.spx_index_load_flat.restype = vp
+        L.spx_index_load_flat.argtypes = [C.c_char_p, i32]
+        L.spx_index_clone.restype = vp
+        L.spx_index_clone.argtypes = [vp, i32]
+        L.spx_index_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
         _LIB = L
     return _LIB
+
+
+def version() -> str:
+    """Layout + kernel version of the loaded library (keys the .spx cache and the measured traffic)."""
+    return lib().spx_version().decode()
 
 
 def _check(rc: int):
@@ -184,9 +202,36 @@ class Index:
             raise SpxError(lib().spx_last_error().decode())
         return cls(h, device)
 
-    def set_text(self, text) -> None:
+    @classmethod
+    def load_flat(cls, path: str, device: int = 0) -> "Index":
+        """An index from a flat-layout cache written by save()."""
+        h = lib().spx_index_load_flat(path.encode(), device)
+        if not h:
+            raise SpxError(lib().spx_last_error().decode())
+        return cls(h, device)
+
+    def save(self, path: str) -> None:
+        _check(lib().spx_index_save(self._h, path.encode()))
+
+    def clone(self, device: int) -> "Index":
+        """A copy of this index on `device` (device-to-device, no re-flattening)."""
+        h = lib().spx_index_clone(self._h, device)
+        if not h:
+            raise SpxError(lib().spx_last_error().decode())
+        return Index(h, device)
+
+    def describe(self) -> dict:
+        import json
+
+        buf = C.create_string_buffer(1024)
+        _check(lib().spx_index_describe(self._h, buf, 1024))
+        return json.loads(buf.value.decode())
+
+    def set_text(self, text, unchecked: bool = False) -> None:
+        """unchecked: skip the text-against-index validation (synthetic indexes that are no text's BWT)."""
         t = text.contiguous()
-        _check(lib().spx_index_set_text(self._h, _t_ptr(t), t.numel(), 1 if t.is_cuda else 0))
+        where = (1 if t.is_cuda else 0) | (SPX_TEXT_UNCHECKED if unchecked else 0)
+        _check(lib().spx_index_set_text(self._h, _t_ptr(t), t.numel(), where))
 
     def close(self):
         h, self._h = self._h, None

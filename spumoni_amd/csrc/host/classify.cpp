@@ -15,6 +15,9 @@
 #include <mutex>
 #include <thread>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "index_files.hpp"
 #include "reads.hpp"
 
@@ -24,34 +27,66 @@ IndexSet::~IndexSet() {
     for (spx_index* p : ix) spx_index_free(p);
 }
 
+static bool file_exists(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    return f.good();
+}
+
+// One flatten (or one read of the flat-layout cache), then device-to-device copies: the reference
+// deserialises its index once per run (pml_t::pml_t / ms_t::ms_t, compute_ms_pml.cpp:700-721, 755-786);
+// N devices cost one load plus N-1 peer copies, not N loads.
+//   SPUMONI_CACHE=use (default)  read <ref>.{pml,ms}[.doc].spx when it is there
+//   SPUMONI_CACHE=write          also write it after flattening the raw / serialised files
+//   SPUMONI_CACHE=off            never touch it
 void IndexSet::load(const RunOptions& o) {
-    RawIndex raw;
-    std::string err;
-    if (!load_raw_index(o.ref_file, o.ms, raw, err)) {
-        // no raw run files: fall back to the serialised index the reference's `run` loads
-        std::string err2;
-        RawIndex ser;
-        if (!load_serialized_index(o.ref_file + (o.ms ? ".thrbv.ms" : ".thrbv.spumoni"), o.ms, ser, err2))
-            fatal_error("%s\n       and %s", err.c_str(), err2.c_str());
-        raw = std::move(ser);
+    const char* pol = std::getenv("SPUMONI_CACHE");
+    const std::string policy = pol ? pol : "use";
+    const std::string cache = o.ref_file + (o.ms ? ".ms" : ".pml") + (o.use_doc ? ".doc" : "") + ".spx";
+    const int dev0 = o.devices.empty() ? 0 : o.devices[0];
+    spx_index* first = nullptr;
+    if (policy != "off" && file_exists(cache)) {
+        first = spx_index_load_flat(cache.c_str(), dev0);
+        if (!first)
+            std::fprintf(stderr, "\n[spumoni-gpu] %s not used (%s): flattening the index files instead\n", cache.c_str(),
+                         spx_last_error());
+        else
+            from_cache = true;
     }
-    if (o.use_doc && !load_doc_array(o.ref_file + ".doc", raw, err)) fatal_error("%s", err.c_str());
-    std::vector<uint8_t> text;
-    if (o.ms) {
-        if (o.text_file.empty() || !read_whole_file(o.text_file, text))
-            fatal_error("MS lengths need the indexed text as a plain file (set SPUMONI_TEXT): the SLP of the\n"
-                        "       reference is replaced by plain text in GPU memory (see DESIGN.md)");
+    if (!first) {
+        RawIndex raw;
+        std::string err;
+        if (!load_raw_index(o.ref_file, o.ms, raw, err)) {
+            // no raw run files: fall back to the serialised index the reference's `run` loads
+            std::string err2;
+            RawIndex ser;
+            if (!load_serialized_index(o.ref_file + (o.ms ? ".thrbv.ms" : ".thrbv.spumoni"), o.ms, ser, err2))
+                fatal_error("%s\n       and %s", err.c_str(), err2.c_str());
+            raw = std::move(ser);
+        }
+        if (o.use_doc && !load_doc_array(o.ref_file + ".doc", raw, err)) fatal_error("%s", err.c_str());
+        std::vector<uint8_t> text;
+        if (o.ms) {
+            if (o.text_file.empty() || !read_whole_file(o.text_file, text))
+                fatal_error("MS lengths need the indexed text as a plain file (set SPUMONI_TEXT): the SLP of the\n"
+                            "       reference is replaced by plain text in GPU memory (see DESIGN.md)");
+        }
+        first = spx_index_from_runs(raw.heads.data(), raw.lens.data(), raw.thr.data(), raw.heads.size(),
+                                    o.ms ? raw.ssa.data() : nullptr, o.ms ? raw.esa.data() : nullptr,
+                                    o.use_doc ? raw.doc_start.data() : nullptr,
+                                    o.use_doc ? raw.doc_end.data() : nullptr, 0, dev0);
+        if (!first) fatal_error("%s", spx_last_error());
+        // the text is checked against the index (length, and text[samples_start[k]] == head of run k):
+        // a text that is not the indexed one is refused instead of giving wrong .lengths
+        if (o.ms && spx_index_set_text(first, text.data(), text.size(), 0) != SPX_OK)
+            fatal_error("%s (SPUMONI_TEXT must be the exact text the index was built from)", spx_last_error());
+        if (policy == "write" && spx_index_save(first, cache.c_str()) != SPX_OK)
+            std::fprintf(stderr, "\n[spumoni-gpu] could not write %s: %s\n", cache.c_str(), spx_last_error());
     }
-    n = raw.n;
-    r = raw.heads.size();
-    for (int dev : o.devices) {
-        spx_index* p = spx_index_from_runs(raw.heads.data(), raw.lens.data(), raw.thr.data(), r,
-                                           o.ms ? raw.ssa.data() : nullptr, o.ms ? raw.esa.data() : nullptr,
-                                           o.use_doc ? raw.doc_start.data() : nullptr,
-                                           o.use_doc ? raw.doc_end.data() : nullptr, 0, dev);
+    ix.push_back(first);
+    if (spx_index_stats(first, &n, &r) != SPX_OK) fatal_error("%s", spx_last_error());
+    for (size_t d = 1; d < o.devices.size(); ++d) {
+        spx_index* p = spx_index_clone(first, o.devices[d]);
         if (!p) fatal_error("%s", spx_last_error());
-        if (o.ms && spx_index_set_text(p, text.data(), text.size(), 0) != SPX_OK)
-            fatal_error("%s", spx_last_error());
         ix.push_back(p);
     }
 }
@@ -68,28 +103,72 @@ size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promot
 namespace {
 
 // "<value> " for every value, the way std::ostream_iterator<size_t>(file, " ") writes them
+// (compute_ms_pml.cpp:1003-1010, 1190-1195).  At GPU speed, turning numbers into text IS the job
+// (4 * 10^6 reads x 200 values = 2 GB of text): digits come two at a time from a table and go
+// straight into a raw buffer whose worst case was reserved per read.
+static const char DIGIT_PAIRS[] =
+    "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+    "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
 struct TextBuf {
-    std::string s;
+    std::vector<char> buf;
+    size_t len = 0;
+    char* reserve(size_t more) {
+        if (len + more > buf.size()) buf.resize(std::max(buf.size() * 2, len + more + (1u << 20)));
+        return buf.data() + len;
+    }
     void header(const std::string& id) {
-        s.push_back('>');
-        s.append(id);
-        s.push_back('\n');
+        char* p = reserve(id.size() + 2);
+        *p++ = '>';
+        std::memcpy(p, id.data(), id.size());
+        p[id.size()] = '\n';
+        len += id.size() + 2;
     }
-    void u64(uint64_t v) {
-        char tmp[24];
-        int p = 24;
-        do {
-            tmp[--p] = (char)('0' + v % 10);
-            v /= 10;
-        } while (v);
-        s.append(tmp + p, 24 - p);
-        s.push_back(' ');
+    static inline char* put(char* p, uint64_t v) {  // decimal digits of v and a blank
+        if (v < 10) {
+            *p++ = (char)('0' + v);
+        } else if (v < 100) {
+            std::memcpy(p, DIGIT_PAIRS + 2 * v, 2);
+            p += 2;
+        } else if (v < 10000) {
+            const uint32_t hi = (uint32_t)v / 100, lo = (uint32_t)v % 100;
+            if (hi >= 10) {
+                std::memcpy(p, DIGIT_PAIRS + 2 * hi, 2);
+                p += 2;
+            } else {
+                *p++ = (char)('0' + hi);
+            }
+            std::memcpy(p, DIGIT_PAIRS + 2 * lo, 2);
+            p += 2;
+        } else {
+            char tmp[24];
+            int q = 24;
+            while (v >= 100) {
+                q -= 2;
+                std::memcpy(tmp + q, DIGIT_PAIRS + 2 * (v % 100), 2);
+                v /= 100;
+            }
+            if (v >= 10) {
+                q -= 2;
+                std::memcpy(tmp + q, DIGIT_PAIRS + 2 * v, 2);
+            } else {
+                tmp[--q] = (char)('0' + v);
+            }
+            std::memcpy(p, tmp + q, 24 - q);
+            p += 24 - q;
+        }
+        *p++ = ' ';
+        return p;
     }
-    void newline() { s.push_back('\n'); }
-    void flush(std::ofstream& f) {
-        f.write(s.data(), (std::streamsize)s.size());
-        s.clear();
+    template <class T>
+    void values(const T* v, uint64_t count) {  // "<v0> <v1> ... \n"
+        char* p0 = reserve(count * (sizeof(T) > 4 ? 21 : 11) + 1);
+        char* p = p0;
+        for (uint64_t i = 0; i < count; ++i) p = put(p, v[i]);
+        *p++ = '\n';
+        len += (size_t)(p - p0);
     }
+    void clear() { len = 0; }
 };
 
 // grow-only buffer in page-locked host memory (spx_host_alloc): copies to and from the GPU
@@ -160,14 +239,16 @@ struct Results {
     std::vector<uint64_t> beg, end;
 };
 
-// contiguous, character-balanced shards: one per device, run concurrently
-void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
+// One super-batch on one device (the worker thread of that device calls this): the batch form of the
+// reference's loop body -- [digestion +] matching_statistics + bin classification
+// (compute_ms_pml.cpp:916-995).
+void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
     const size_t nreads = sb.nreads();
     const uint64_t total = sb.offs.back();
     const bool digest = o.use_promotions || o.use_dna_letters;
     const int kind = o.use_promotions ? SPX_DIGEST_PROMOTED : SPX_DIGEST_DNA;
-    // with digestion a shard's results are laid out at the digested offsets, inside a region as
-    // large as its worst case (every k-mer reported: 1 byte each for -m, k letters for -a)
+    // with digestion the results are laid out at the digested offsets, inside a region as large as
+    // the worst case (every k-mer reported: 1 byte each for -m, k letters for -a)
     const uint64_t grow = digest && o.use_dna_letters ? (uint64_t)o.k : 1;
     res.lengths.resize_uninit(total * grow);
     if (o.ms) res.pointers.resize_uninit(total * grow);
@@ -175,60 +256,66 @@ void run_on_devices(IndexSet& set, const RunOptions& o, const SuperBatch& sb, si
     if (o.write_report) res.cls.resize_uninit(nreads);
     res.beg.resize(nreads);
     res.end.resize(nreads);
-    const size_t ndev = set.ix.size();
-    std::vector<size_t> cut(ndev + 1, nreads);
-    cut[0] = 0;
-    for (size_t d = 1; d < ndev; ++d) {
-        const uint64_t target = total * d / ndev;
-        size_t c = std::lower_bound(sb.offs.begin(), sb.offs.end() - 1, target) - sb.offs.begin();
-        cut[d] = std::max(cut[d - 1], std::min(c, nreads));
-    }
-    std::vector<std::string> errors(ndev);
-    auto work = [&](size_t d) {
-        const size_t lo = cut[d], hi = cut[d + 1];
-        if (hi <= lo) return;
-        const uint64_t a = sb.offs[lo];
-        std::vector<uint64_t> offs(hi - lo + 1);
-        for (size_t q = lo; q <= hi; ++q) offs[q - lo] = sb.offs[q] - a;
-        const uint64_t ra = a * grow;  // where this shard's results start
-        int rc;
-        if (!digest) {
-            rc = spx_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data() + a, offs.data(),
-                                 hi - lo, res.lengths.data() + ra, o.ms ? res.pointers.data() + ra : nullptr,
-                                 o.use_doc ? res.docs.data() + ra : nullptr,
-                                 o.write_report ? res.cls.data() + lo : nullptr, o.bin_size, max_value_thr);
-            for (size_t q = lo; q < hi; ++q) {
-                res.beg[q] = sb.offs[q];
-                res.end[q] = sb.offs[q + 1];
-            }
-        } else {
-            // perform_minimizer_digestion / perform_dna_minimizer_digestion + matching_statistics
-            // (compute_ms_pml.cpp:919-938), the batch on the device in one call
-            std::vector<uint64_t> doffs(hi - lo + 1);
-            rc = spx_digest_query_batch(set.ix[d], o.ms ? SPX_MODE_MS : SPX_MODE_PML, kind, (uint32_t)o.k,
-                                        (uint32_t)o.w, sb.seqs.data() + a, offs.data(), hi - lo, doffs.data(),
-                                        (sb.offs[hi] - a) * grow, res.lengths.data() + ra,
-                                        o.ms ? res.pointers.data() + ra : nullptr,
-                                        o.use_doc ? res.docs.data() + ra : nullptr,
-                                        o.write_report ? res.cls.data() + lo : nullptr, o.bin_size, max_value_thr);
-            if (rc == SPX_OK)
-                for (size_t q = lo; q < hi; ++q) {
-                    res.beg[q] = ra + doffs[q - lo];
-                    res.end[q] = ra + doffs[q - lo + 1];
-                }
+    int rc;
+    if (!digest) {
+        rc = spx_query_batch(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
+                             res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
+                             o.use_doc ? res.docs.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
+                             o.bin_size, max_value_thr);
+        for (size_t q = 0; q < nreads; ++q) {
+            res.beg[q] = sb.offs[q];
+            res.end[q] = sb.offs[q + 1];
         }
-        if (rc != SPX_OK) errors[d] = spx_last_error();
-    };
-    std::vector<std::thread> th;
-    for (size_t d = 1; d < ndev; ++d) th.emplace_back(work, d);
-    work(0);
-    for (auto& t : th) t.join();
-    for (auto& e : errors)
-        if (!e.empty()) fatal_error("%s", e.c_str());
+    } else {
+        // perform_minimizer_digestion / perform_dna_minimizer_digestion + matching_statistics
+        // (compute_ms_pml.cpp:919-938), the batch on the device in one call
+        std::vector<uint64_t> doffs(nreads + 1);
+        rc = spx_digest_query_batch(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, kind, (uint32_t)o.k, (uint32_t)o.w,
+                                    sb.seqs.data(), sb.offs.data(), nreads, doffs.data(), total * grow,
+                                    res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
+                                    o.use_doc ? res.docs.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
+                                    o.bin_size, max_value_thr);
+        if (rc == SPX_OK)
+            for (size_t q = 0; q < nreads; ++q) {
+                res.beg[q] = doffs[q];
+                res.end[q] = doffs[q + 1];
+            }
+    }
+    if (rc != SPX_OK) fatal_error("%s", spx_last_error());
 }
 
+// The four output files as plain descriptors with a running end offset each: a super-batch is
+// formatted by several host threads into their own buffers, the buffers' sizes are prefix-summed,
+// and every thread pwrite()s its part at its own offset -- no concatenation, no serial write.
+struct OutFile {
+    int fd = -1;
+    uint64_t end = 0;
+    void open(const std::string& path) {
+        fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) fatal_error("cannot create %s", path.c_str());
+        end = 0;
+    }
+    bool is_open() const { return fd >= 0; }
+    void write_at(const char* p, size_t n, uint64_t at) const {
+        while (n > 0) {
+            const ssize_t w = ::pwrite(fd, p, n, (off_t)at);
+            if (w <= 0) fatal_error("write failed (disk full?)");
+            p += w;
+            n -= (size_t)w;
+            at += (uint64_t)w;
+        }
+    }
+    void append(const std::string& s) {
+        write_at(s.data(), s.size(), end);
+        end += s.size();
+    }
+    ~OutFile() {
+        if (fd >= 0) ::close(fd);
+    }
+};
+
 struct Outputs {
-    std::ofstream lengths, pointers, docs, report;
+    OutFile lengths, pointers, docs, report;
 };
 
 // Formats reads [lo, hi) of a super-batch into text; run by several host threads at once
@@ -241,20 +328,22 @@ struct TextChunk {
 void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res, size_t lo, size_t hi,
                   TextChunk& out) {
     std::ostringstream rep;
+    out.tl.clear();
+    out.tp.clear();
+    out.td.clear();
     for (size_t q = lo; q < hi; ++q) {
         const uint64_t a = res.beg[q], b = res.end[q];
         if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
             out.td.header(sb.ids[q]);
-            for (uint64_t i = a; i < b; ++i) out.td.u64(res.docs[i]);
-            out.td.newline();
+            out.td.values(res.docs.data() + a, b - a);
         }
-        out.tl.header(sb.ids[q]);  // :1008-1010
-        for (uint64_t i = a; i < b; ++i) out.tl.u64(res.lengths[i]);
-        out.tl.newline();
+        if (!o.report_only) {
+            out.tl.header(sb.ids[q]);  // :1008-1010
+            out.tl.values(res.lengths.data() + a, b - a);
+        }
         if (o.ms) {  // :1190-1195
             out.tp.header(sb.ids[q]);
-            for (uint64_t i = a; i < b; ++i) out.tp.u64(res.pointers[i]);
-            out.tp.newline();
+            out.tp.values(res.pointers.data() + a, b - a);
         }
         if (o.write_report) {  // :1012-1020
             const spx_class& c = res.cls[q];
@@ -270,30 +359,60 @@ void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res,
     out.report = rep.str();
 }
 
-void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res) {
+void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res,
+                   std::vector<TextChunk>& chunks) {
     const size_t nreads = sb.nreads();
-    size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
-    std::vector<TextChunk> chunks(nt);
-    std::vector<std::thread> th;
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
+    if (chunks.size() < nt) chunks.resize(nt);
+    // where thread t's text goes in each file: known once every thread has formatted its part
+    std::vector<uint64_t> at_l(nt + 1), at_p(nt + 1), at_d(nt + 1), at_r(nt + 1);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t formatted = 0;
+    bool placed = false;
     auto lo_of = [&](size_t t) { return nreads * t / nt; };
-    for (size_t t = 1; t < nt; ++t)
-        th.emplace_back([&, t]() { format_range(o, sb, res, lo_of(t), lo_of(t + 1), chunks[t]); });
-    format_range(o, sb, res, lo_of(0), lo_of(1), chunks[0]);
+    auto work = [&](size_t t) {
+        TextChunk& c = chunks[t];
+        format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
+        {
+            std::unique_lock<std::mutex> g(mu);
+            if (++formatted == nt) {  // the last one to finish lays the chunks out, in input order
+                at_l[0] = out.lengths.end;
+                at_p[0] = out.pointers.end;
+                at_d[0] = out.docs.end;
+                at_r[0] = out.report.end;
+                for (size_t i = 0; i < nt; ++i) {
+                    at_l[i + 1] = at_l[i] + chunks[i].tl.len;
+                    at_p[i + 1] = at_p[i] + chunks[i].tp.len;
+                    at_d[i + 1] = at_d[i] + chunks[i].td.len;
+                    at_r[i + 1] = at_r[i] + chunks[i].report.size();
+                }
+                placed = true;
+                cv.notify_all();
+            } else {
+                cv.wait(g, [&] { return placed; });
+            }
+        }
+        if (c.tl.len) out.lengths.write_at(c.tl.buf.data(), c.tl.len, at_l[t]);
+        if (o.ms && c.tp.len) out.pointers.write_at(c.tp.buf.data(), c.tp.len, at_p[t]);
+        if (o.use_doc && c.td.len) out.docs.write_at(c.td.buf.data(), c.td.len, at_d[t]);
+        if (o.write_report && !c.report.empty()) out.report.write_at(c.report.data(), c.report.size(), at_r[t]);
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
     for (auto& x : th) x.join();
-    for (TextChunk& c : chunks) {  // written in input order (the reference's -t 1 order)
-        c.tl.flush(out.lengths);
-        if (o.ms) c.tp.flush(out.pointers);
-        if (o.use_doc) c.td.flush(out.docs);
-        if (o.write_report) out.report.write(c.report.data(), (std::streamsize)c.report.size());
-    }
-    if (o.write_report) out.report.flush();
+    out.lengths.end = at_l[nt];
+    out.pointers.end = at_p[nt];
+    out.docs.end = at_d[nt];
+    out.report.end = at_r[nt];
 }
 
 size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
     out.lengths.open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
     if (o.ms) out.pointers.open(o.pattern_file + ".pointers");
     if (o.use_doc) out.docs.open(o.pattern_file + ".doc_numbers");
-    if (o.write_report) out.report.open(o.pattern_file + ".report", std::ofstream::out);
+    if (o.write_report) out.report.open(o.pattern_file + ".report");
     double percentile = 0.0;
     std::string err;
     // the reference does not check the stream either (:867-869): a missing null database
@@ -301,11 +420,13 @@ size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
     (void)load_null_db(o.ref_file + (o.ms ? ".msnulldb" : ".pmlnulldb"), percentile, err);
     const size_t max_value_thr = max_value_threshold(percentile, !o.ms, o.use_promotions, o.use_dna_letters);
     if (o.write_report) {  // :877-886
-        out.report.precision(4);
-        out.report << std::setw(30) << std::left << "read id:" << std::setw(15) << std::left << "status:"
-                   << std::setw(19) << std::left << "avg max-value (thr=" << std::setw(2) << std::left
-                   << max_value_thr << std::setw(5) << std::left << "):" << std::setw(12) << std::left
-                   << "above thr:" << std::setw(12) << std::left << "below thr:" << std::endl;
+        std::ostringstream hd;
+        hd.precision(4);
+        hd << std::setw(30) << std::left << "read id:" << std::setw(15) << std::left << "status:"
+           << std::setw(19) << std::left << "avg max-value (thr=" << std::setw(2) << std::left
+           << max_value_thr << std::setw(5) << std::left << "):" << std::setw(12) << std::left
+           << "above thr:" << std::setw(12) << std::left << "below thr:" << std::endl;
+        out.report.append(hd.str());
     }
     return max_value_thr;
 }
@@ -318,6 +439,7 @@ namespace {
 struct Slot {
     SuperBatch sb;
     Results res;
+    uint64_t seq = 0;            // position of this super-batch in the input (results are written in this order)
     bool last = false;           // no more input after this one
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
@@ -432,7 +554,7 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
 }  // namespace
 
 namespace {
-struct StageTimer {  // SPUMONI_TIMING=1: per-stage wall time on stderr (ours)
+struct StageTimer {  // per-stage wall time on stderr (ours)
     const char* name;
     double total = 0;
     std::chrono::steady_clock::time_point t0;
@@ -441,32 +563,65 @@ struct StageTimer {  // SPUMONI_TIMING=1: per-stage wall time on stderr (ours)
 };
 }  // namespace
 
+// Re-sequences the super-batches the device workers finish, in whatever order, into input order.
+class OrderedDone {
+public:
+    void put(uint64_t seq, int slot) {
+        std::lock_guard<std::mutex> g(mu_);
+        done_.emplace_back(seq, slot);
+        cv_.notify_all();
+    }
+    int take(uint64_t seq) {  // blocks until super-batch `seq` is done
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+            for (size_t i = 0; i < done_.size(); ++i)
+                if (done_[i].first == seq) {
+                    const int slot = done_[i].second;
+                    done_.erase(done_.begin() + (long)i);
+                    return slot;
+                }
+            cv_.wait(g);
+        }
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::pair<uint64_t, int>> done_;
+};
+
 size_t classify_reads(IndexSet& set, const RunOptions& o) {
     Outputs out;
     const size_t max_value_thr = open_outputs_and_threshold(out, o);
-    const bool timing = std::getenv("SPUMONI_TIMING") != nullptr;
-    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_gpu{"gpu (incl. copies)", 0, {}},
-        t_write{"format+write", 0, {}};
+    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_write{"format+write", 0, {}};
     t_load.start();
     ReadFile input(o.pattern_file);
     t_load.stop();
-    // three stages, three slots: the host parses super-batch i+1 and formats/writes i-1 while
-    // the GPUs walk super-batch i; results are written in input order
-    constexpr int NSLOTS = 3;
-    std::vector<Slot> slots(NSLOTS);
-    SlotQueue free_q, parsed_q, computed_q;
+    // Parser -> ONE queue of parsed super-batches -> one worker thread per device -> ordered writer.
+    // Every device pulls its next super-batch when it is free (reads are independent,
+    // compute_ms_pml.cpp:907-938: nothing is carried from one read to the next), so a slower or busier
+    // device simply takes fewer of them; the writer puts the results back into input order (the
+    // reference's -t 1 order).  Slots: one being parsed, one per device, one being written, and one
+    // more per device so that no device waits for the parser.
+    const size_t ndev = set.ix.size();
+    const int NSLOTS = (int)(2 * ndev + 2);
+    std::vector<Slot> slots((size_t)NSLOTS);
+    SlotQueue free_q, parsed_q;
+    OrderedDone done;
     for (int i = 0; i < NSLOTS; ++i) free_q.push(i);
     size_t num_reads = 0;
-    std::thread gpu([&] {
+    std::vector<double> dev_busy(ndev, 0.0);
+    std::vector<size_t> dev_batches(ndev, 0);
+    auto device_worker = [&](size_t d) {
         for (;;) {
             const int i = parsed_q.pop();
             if (i < 0) break;
-            t_gpu.start();
-            if (slots[i].sb.nreads() > 0) run_on_devices(set, o, slots[i].sb, max_value_thr, slots[i].res);
+            const auto t0 = std::chrono::steady_clock::now();
+            Slot& s = slots[(size_t)i];
+            if (s.sb.nreads() > 0) run_on_device(set.ix[d], o, s.sb, max_value_thr, s.res);
             if (o.use_promotions || o.use_dna_letters) {
                 // a read that digests to nothing is fatal where the reference meets it (:926-931):
                 // everything before it is still written
-                Slot& s = slots[i];
                 for (size_t q = 0; q < s.sb.nreads(); ++q)
                     if (s.res.beg[q] == s.res.end[q]) {
                         s.deferred = 2;
@@ -476,53 +631,54 @@ size_t classify_reads(IndexSet& set, const RunOptions& o) {
                         break;
                     }
             }
-            t_gpu.stop();
-            computed_q.push(i);
+            dev_busy[d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            dev_batches[d]++;
+            done.put(s.seq, i);
         }
-        computed_q.push(-1);
-    });
+    };
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < ndev; ++d) workers.emplace_back(device_worker, d);
     std::thread writer([&] {
-        for (;;) {
-            const int i = computed_q.pop();
-            if (i < 0) break;
-            Slot& s = slots[i];
+        std::vector<TextChunk> chunks;  // formatting buffers, kept across super-batches
+        for (uint64_t seq = 0;; ++seq) {
+            const int i = done.take(seq);
+            Slot& s = slots[(size_t)i];
             t_write.start();
-            if (s.sb.nreads() > 0) write_results(out, o, s.sb, s.res);
+            if (s.sb.nreads() > 0) write_results(out, o, s.sb, s.res, chunks);
             t_write.stop();
             num_reads += s.sb.nreads();
-            if (s.deferred == 1) {
-                out.lengths.flush();
-                fatal_error("%s", s.deferred_msg.c_str());
-            }
+            if (s.deferred == 1) fatal_error("%s", s.deferred_msg.c_str());
             if (s.deferred == 2) {
-                out.lengths.flush();
-                out.pointers.flush();
-                out.docs.flush();
-                out.report.flush();
                 std::cout << "\n\n";
                 fatal_warning("%s was empty after digestion, commonly due to reads "
                               "consisting of mostly non-ACGT characters. Please remove "
                               "read or run SPUMONI without minimizer digestion.", s.deferred_msg.data());
             }
+            const bool last = s.last;
             free_q.push(i);
+            if (last) break;
         }
     });
     bool input_done = false;
-    for (;;) {
+    for (uint64_t seq = 0;; ++seq) {
         const int i = free_q.pop();
         t_parse.start();
-        fill_slot(input, o, slots[i], input_done);
+        fill_slot(input, o, slots[(size_t)i], input_done);
         t_parse.stop();
-        const bool last = slots[i].last;
+        slots[(size_t)i].seq = seq;
+        const bool last = slots[(size_t)i].last;
         parsed_q.push(i);
         if (last) break;
     }
-    parsed_q.push(-1);
-    gpu.join();
+    for (size_t d = 0; d < ndev; ++d) parsed_q.push(-1);
+    for (auto& w : workers) w.join();
     writer.join();
-    if (timing)
-        for (StageTimer* t : {&t_load, &t_parse, &t_gpu, &t_write})
-            std::fprintf(stderr, "[timing] %-20s %.3f s\n", t->name, t->total);
+    // per-stage wall times (ours, additive; stages overlap, so they do not add up to the total)
+    for (StageTimer* t : {&t_load, &t_parse, &t_write})
+        std::fprintf(stderr, "[timing] %-22s %.3f s\n", t->name, t->total);
+    for (size_t d = 0; d < ndev; ++d)
+        std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)\n", d,
+                     dev_busy[d], dev_batches[d]);
     return num_reads;
 }
 
@@ -538,11 +694,12 @@ size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
     if (!read_whole_file(o.pattern_file, data)) fatal_error("The following path is not valid: %s", o.pattern_file.data());
     SuperBatch sb;
     Results res;
+    std::vector<TextChunk> chunks;
     size_t num_reads = 0, start = 0;
     auto flush = [&]() {
         if (sb.nreads() == 0) return;
-        run_on_devices(set, oo, sb, 0, res);
-        write_results(out, oo, sb, res);
+        run_on_device(set.ix[0], oo, sb, 0, res);
+        write_results(out, oo, sb, res, chunks);
         sb.clear();
     };
     for (size_t i = 0; i < data.size(); ++i) {

@@ -27,9 +27,11 @@ struct RunOptions {  // SpumoniRunOptions, include/spumoni_main.hpp:233-250
     std::string text_file;
     size_t super_batch_chars = 64u << 20;
     size_t format_threads = 1;  // host threads that turn results into text (-t, or the core count)
+    bool report_only = false;   // SPUMONI_REPORT_ONLY=1 with -c: only <pattern>.report gets content
 };
 
-// One spx_index per device, all built from the same raw index files.
+// One spx_index per device: flattened (or read from the flat-layout cache) once, then replicated
+// device to device.
 class IndexSet {
 public:
     IndexSet() = default;
@@ -40,6 +42,7 @@ public:
     void load(const RunOptions& o);
     std::vector<spx_index*> ix;
     uint64_t n = 0, r = 0;
+    bool from_cache = false;  // the flat arrays came from <ref>.{pml,ms}[.doc].spx
 };
 
 // compute_ms_pml.cpp:871-875 (PML) / :1061-1063 (MS)

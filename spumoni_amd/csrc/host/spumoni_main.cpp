@@ -193,6 +193,29 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
         FORCE_LOG(tag, "input reads will digested using DNA minimizer alphabet (k=%d, w=%d)", (int)o.k, (int)o.w);
     else
         FORCE_LOG(tag, "input reads will be used directly, no minimizer digestion");
+    if (o.use_promotions || o.use_dna_letters) {
+        // the digestion restates dnbaker/bonsai @5273b81a92 (window rule, Lex order, and for -m
+        // the 8-bit character hashes) without bonsai's source or any of its output to check against.
+        // Say so, loudly, every time -- against an index digested by upstream `spumoni build` the results
+        // may be wrong without any other sign.
+        const char* pin = std::getenv("SPUMONI_CHARHASH");
+        std::fprintf(stderr,
+                     "\033[1m\033[33m[spumoni-gpu] WARNING:\033[0m minimizer digestion (-m / -a) is a restatement of bonsai's\n"
+                     "              RollingHasher / Encoder that has NOT been verified against bonsai output (DESIGN.md 4.4).\n"
+                     "              PML/MS values are only guaranteed for an index whose reference was digested by THIS\n"
+                     "              package (spumoni_amd/build_index.py -m/-a).%s\n",
+                     o.use_promotions ? (pin ? "  Character hashes pinned by SPUMONI_CHARHASH."
+                                             : "  Pin the -m character hashes with SPUMONI_CHARHASH=<A>,<C>,<G>,<T>.")
+                                      : "");
+        if (pin && o.use_promotions) {
+            unsigned v[4] = {0, 0, 0, 0};
+            if (std::sscanf(pin, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) != 4)
+                fatal_error("SPUMONI_CHARHASH must be four comma-separated byte values (A,C,G,T)");
+            const int64_t packed = (int64_t)((v[0] & 255) | ((v[1] & 255) << 8) | ((v[2] & 255) << 16) | ((uint64_t)(v[3] & 255) << 24));
+            for (spx_index* p : set.ix)
+                if (spx_set_option(p, "minimizer_charhash", packed) != SPX_OK) fatal_error("%s", spx_last_error());
+        }
+    }
     start_time = std::chrono::system_clock::now();
     STATUS_LOG(tag, o.ms ? "processing the reads" : "processing the patterns");
     size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o);
@@ -220,6 +243,7 @@ static int run_main(int argc, char** argv) {
         if (o.devices.empty()) o.devices.push_back(0);
     }
     if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
+    if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && std::atoi(t) != 0;
     // -t: the reference's helper threads walk the index; here the GPU does, and the threads
     // format the output text instead (default: up to 16 of the available cores)
     o.format_threads = o.threads > 1 ? o.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));

@@ -1,6 +1,7 @@
 // spx_api.hip -- the C-ABI of libspumoni_gpu.so (include/spumoni_gpu.h).
 // No CPU fallback exists anywhere in this library: without a gfx950 device every
 // entry point that needs one returns SPX_E_NODEVICE.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -99,16 +100,10 @@ int spx_device_count(void) { return usable_devices(); }
 void spx_index_free(spx_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    if (ix->rows) (void)hipFree(ix->rows);
-    if (ix->fat) (void)hipFree(ix->fat);
-    if (ix->fat_j) (void)hipFree(ix->fat_j);
-    if (ix->rundocs) (void)hipFree(ix->rundocs);
-    if (ix->q_alloc) (void)hipFree(ix->q_alloc);
-    if (ix->aux) (void)hipFree(ix->aux);
-    if (ix->dirrows) (void)hipFree(ix->dirrows);
-    if (ix->ss_by_run) (void)hipFree(ix->ss_by_run);
-    if (ix->letters) (void)hipFree(ix->letters);
-    if (ix->text) (void)hipFree(ix->text);
+    void** arr[spx_index::NARR];
+    index_arrays(ix, arr);
+    for (void** a : arr)
+        if (*a) (void)hipFree(*a);
     if (ix->counters) (void)hipFree(ix->counters);
     for (auto& st : ix->pipe_s)
         if (st) (void)hipStreamDestroy(st);
@@ -122,6 +117,31 @@ void spx_index_free(spx_index* ix) {
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
     delete ix;
+}
+
+// bonsai's RollingHasher draws its character table from a Mersenne twister seeded with 1337
+// and keeps 8 bits (our reading of CharacterHash, see DESIGN.md 4.4): entry c = c-th output
+static void default_charhash(uint8_t out[4]) {
+    std::mt19937 gen(1337u);
+    uint8_t table[256];
+    for (int c = 0; c < 256; ++c) table[c] = (uint8_t)(gen() & 0xffu);
+    out[0] = table['A'];
+    out[1] = table['C'];
+    out[2] = table['G'];
+    out[3] = table['T'];
+}
+
+// counters, events and knobs every index carries, however its arrays came to be
+static int init_runtime(spx_index* ix) {
+    default_charhash(ix->charhash);
+    if (const char* e = getenv("SPX_WAVES_PER_CU")) ix->waves_per_cu = atoi(e);  // experiment knob
+    SPX_HIP(hipMalloc((void**)&ix->counters, sizeof(WalkCounters)));
+    SPX_HIP(hipMemset(ix->counters, 0, sizeof(WalkCounters)));
+    SPX_HIP(hipEventCreate(&ix->ev0));
+    SPX_HIP(hipEventCreate(&ix->ev1));
+    SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
+    SPX_HIP(hipDeviceSynchronize());
+    return SPX_OK;
 }
 
 static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* lens,
@@ -158,25 +178,7 @@ static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* l
                                (const uint64_t*)dev[4], (const uint64_t*)dev[5],
                                (const uint64_t*)dev[6]);
     if (rc != SPX_OK) return rc;
-    SPX_HIP(hipMalloc((void**)&ix->counters, sizeof(WalkCounters)));
-    SPX_HIP(hipMemset(ix->counters, 0, sizeof(WalkCounters)));
-    SPX_HIP(hipEventCreate(&ix->ev0));
-    SPX_HIP(hipEventCreate(&ix->ev1));
-    SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
-    SPX_HIP(hipDeviceSynchronize());
-    return SPX_OK;
-}
-
-// bonsai's RollingHasher draws its character table from a Mersenne twister seeded with 1337
-// and keeps 8 bits (our reading of CharacterHash, see DESIGN.md 4.4): entry c = c-th output
-static void default_charhash(uint8_t out[4]) {
-    std::mt19937 gen(1337u);
-    uint8_t table[256];
-    for (int c = 0; c < 256; ++c) table[c] = (uint8_t)(gen() & 0xffu);
-    out[0] = table['A'];
-    out[1] = table['C'];
-    out[2] = table['G'];
-    out[3] = table['T'];
+    return init_runtime(ix);
 }
 
 spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr,
@@ -190,8 +192,6 @@ spx_index* spx_index_from_runs(const uint8_t* heads, const uint64_t* lens, const
     }
     spx_index* ix = new spx_index();
     ix->device = device;
-    default_charhash(ix->charhash);
-    if (const char* e = getenv("SPX_WAVES_PER_CU")) ix->waves_per_cu = atoi(e);  // experiment knob
     if (from_runs_impl(ix, heads, lens, thr, r, ssa, esa, doc_start, doc_end, where) != SPX_OK) {
         spx_index_free(ix);
         return nullptr;
@@ -266,15 +266,48 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
         set_error("null argument");
         return SPX_E_ARG;
     }
+    const bool unchecked = (where & SPX_TEXT_UNCHECKED) != 0;
+    where &= ~SPX_TEXT_UNCHECKED;
+    if (!unchecked && n_text + 1 != ix->n) {
+        // the BWT of a text of n_text characters plus its terminator has n_text + 1 positions
+        set_error("text has %llu characters but the index was built over %llu (+ terminator): not the indexed text",
+                  (unsigned long long)n_text, (unsigned long long)(ix->n - 1));
+        return SPX_E_FORMAT;
+    }
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
     if (ix->text) (void)hipFree(ix->text);
     ix->text = nullptr;
+    ix->n_text = 0;
+    bind_view(ix);
     SPX_HIP(hipMalloc((void**)&ix->text, n_text + 16));
     SPX_HIP(hipMemcpy(ix->text, text, n_text, where ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    SPX_HIP(hipMemset(ix->text + n_text, 0, 16));
     ix->n_text = n_text;
-    ix->view.text = ix->text;
-    ix->view.n_text = n_text;
+    ix->arr_bytes[A_TEXT] = n_text + 16;
+    bind_view(ix);
+    if (!unchecked && ix->has_samples) {
+        // every run's first BWT character is the text character in front of its suffix:
+        // text[samples_start[k]] == head of run k, for all r runs (one pass over the samples)
+        unsigned long long* d_bad = nullptr;
+        SPX_HIP(hipMalloc((void**)&d_bad, 8));
+        SPX_HIP(hipMemset(d_bad, 0, 8));
+        int rc = launch_text_check(ix, d_bad, nullptr);
+        unsigned long long bad = 0;
+        if (rc == SPX_OK && hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SPX_E_HIP;
+        (void)hipFree(d_bad);
+        if (rc != SPX_OK) return rc;
+        if (bad) {
+            (void)hipFree(ix->text);
+            ix->text = nullptr;
+            ix->n_text = 0;
+            ix->arr_bytes[A_TEXT] = 0;
+            bind_view(ix);
+            set_error("text disagrees with the index at %llu of %llu runs (text[samples_start[k]] must be the head "
+                      "of run k): not the text this index was built from", bad, (unsigned long long)ix->r);
+            return SPX_E_FORMAT;
+        }
+    }
     return SPX_OK;
 }
 
@@ -336,6 +369,10 @@ int spx_digest_batch_device(spx_index* ix, int kind, uint32_t k, uint32_t w, con
         set_error("null argument");
         return SPX_E_ARG;
     }
+    if (((uintptr_t)d_seqs & 15) != 0) {
+        set_error("d_seqs must be 16-byte aligned (and readable for round_up(total_chars, 16) + 16 bytes)");
+        return SPX_E_ARG;
+    }
     if (out_capacity < spx_digest_capacity(kind, k, total_chars)) {
         set_error("d_out_seqs must hold spx_digest_capacity() = %llu bytes",
                   (unsigned long long)spx_digest_capacity(kind, k, total_chars));
@@ -374,7 +411,7 @@ int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint
     const uint64_t cap = spx_digest_capacity(kind, k, total);
     void *dseq = nullptr, *doff = nullptr, *dout = nullptr, *dooff = nullptr;
     int rc;
-    if ((rc = ensure_scratch(ix, 6, total + 16, &dseq)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 6, ((total + 15) & ~15ull) + 16, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 0, cap, &dout)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
@@ -693,7 +730,7 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     const uint64_t total = nreads ? offsets[nreads] : 0;
     const uint64_t cap = spx_digest_capacity(kind, k, total);
     void *draw = nullptr, *doff = nullptr, *dseq = nullptr, *dooff = nullptr;
-    if ((rc = ensure_scratch(ix, 6, total + 16, &draw)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 6, ((total + 15) & ~15ull) + 16, &draw)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 0, cap, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
@@ -712,6 +749,290 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     // the digested reads never leave the device: the walk starts from the scratch buffers
     return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)dooff, nreads, dtotal, out_lengths,
                          out_pointers, out_docs, out_class, bin_width, max_value_thr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat-layout cache (.spx) and replication: the device arrays of an index as they are
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct SpxFileHeader {
+    char magic[8];        // "SPXFLAT\0"
+    char layout[56];      // spx_version(): a cache written by another layout is refused
+    uint64_t header_bytes;
+    uint64_t n, r;
+    uint32_t has_samples, has_docs;
+    uint64_t n_text;
+    uint64_t arr_bytes[spx_index::NARR];
+    uint64_t arr_offset[spx_index::NARR];  // file offsets, 4096-aligned
+    spx::DevIndex view;   // scalars; the pointers inside are rebound on load
+    uint64_t device_bytes;
+};
+
+constexpr size_t STAGE = 64u << 20;
+
+// file -> device through two page-locked staging buffers (read of chunk i+1 overlaps copy of chunk i)
+int read_to_device(FILE* f, uint64_t off, void* dst, uint64_t bytes, void* stage[2], hipStream_t st, hipEvent_t ev[2]) {
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0) {
+        set_error("seek failed");
+        return SPX_E_IO;
+    }
+    int b = 0;
+    for (uint64_t done = 0; done < bytes; b ^= 1) {
+        const size_t take = (size_t)std::min<uint64_t>(STAGE, bytes - done);
+        SPX_HIP(hipEventSynchronize(ev[b]));  // the copy that last used this buffer
+        if (fread(stage[b], 1, take, f) != take) {
+            set_error("cache file is truncated");
+            return SPX_E_IO;
+        }
+        SPX_HIP(hipMemcpyAsync((char*)dst + done, stage[b], take, hipMemcpyHostToDevice, st));
+        SPX_HIP(hipEventRecord(ev[b], st));
+        done += take;
+    }
+    return SPX_OK;
+}
+
+int write_from_device(FILE* f, const void* src, uint64_t bytes, void* stage[2], hipStream_t st, hipEvent_t ev[2]) {
+    // device -> host copy of chunk i+1 overlaps the fwrite of chunk i
+    uint64_t issued = 0, written = 0;
+    size_t len[2] = {0, 0};
+    int b = 0;
+    auto issue = [&](int buf) -> int {
+        len[buf] = (size_t)std::min<uint64_t>(STAGE, bytes - issued);
+        SPX_HIP(hipMemcpyAsync(stage[buf], (const char*)src + issued, len[buf], hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipEventRecord(ev[buf], st));
+        issued += len[buf];
+        return SPX_OK;
+    };
+    if (bytes == 0) return SPX_OK;
+    int rc = issue(0);
+    if (rc != SPX_OK) return rc;
+    while (written < bytes) {
+        if (issued < bytes && (rc = issue(b ^ 1)) != SPX_OK) return rc;
+        SPX_HIP(hipEventSynchronize(ev[b]));
+        if (fwrite(stage[b], 1, len[b], f) != len[b]) {
+            set_error("write failed (disk full?)");
+            return SPX_E_IO;
+        }
+        written += len[b];
+        b ^= 1;
+    }
+    return SPX_OK;
+}
+
+struct Staging {  // two pinned buffers + a stream + two events, released on scope exit
+    void* stage[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int init() {
+        for (int i = 0; i < 2; ++i) {
+            SPX_HIP(hipHostMalloc(&stage[i], STAGE, hipHostMallocDefault));
+            SPX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        SPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return SPX_OK;
+    }
+    ~Staging() {
+        for (int i = 0; i < 2; ++i) {
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+}  // namespace
+
+const char* spx_version(void) { return SPX_LAYOUT_VERSION; }
+
+int spx_index_save(spx_index* ix, const char* path) {
+    if (!ix || !path) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    SPX_HIP(hipDeviceSynchronize());
+    SpxFileHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "SPXFLAT", 8);
+    snprintf(h.layout, sizeof h.layout, "%s", SPX_LAYOUT_VERSION);
+    h.header_bytes = sizeof h;
+    h.n = ix->n;
+    h.r = ix->r;
+    h.has_samples = ix->has_samples;
+    h.has_docs = ix->has_docs;
+    h.n_text = ix->n_text;
+    h.view = ix->view;
+    {  // the file holds no addresses: the pointers are rebound on load (bind_view)
+        spx_index blank;
+        blank.view = h.view;
+        blank.n_text = ix->n_text;
+        bind_view(&blank);
+        h.view = blank.view;
+    }
+    h.device_bytes = ix->device_bytes;
+    uint64_t off = (sizeof h + 4095) & ~4095ull;
+    for (int i = 0; i < spx_index::NARR; ++i) {
+        h.arr_bytes[i] = ix->arr_bytes[i];
+        h.arr_offset[i] = off;
+        off = (off + ix->arr_bytes[i] + 4095) & ~4095ull;
+    }
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) {
+        set_error("cannot create %s", tmp.c_str());
+        return SPX_E_IO;
+    }
+    Staging sg;
+    int rc = sg.init();
+    if (rc == SPX_OK && fwrite(&h, sizeof h, 1, f) != 1) {
+        set_error("write failed");
+        rc = SPX_E_IO;
+    }
+    void** arr[spx_index::NARR];
+    index_arrays(ix, arr);
+    for (int i = 0; i < spx_index::NARR && rc == SPX_OK; ++i) {
+        if (fseeko(f, (off_t)h.arr_offset[i], SEEK_SET) != 0) {
+            set_error("seek failed");
+            rc = SPX_E_IO;
+            break;
+        }
+        rc = write_from_device(f, *arr[i], h.arr_bytes[i], sg.stage, sg.st, sg.ev);
+    }
+    if (fclose(f) != 0 && rc == SPX_OK) {
+        set_error("write failed (disk full?)");
+        rc = SPX_E_IO;
+    }
+    if (rc == SPX_OK && rename(tmp.c_str(), path) != 0) {
+        set_error("cannot rename %s to %s", tmp.c_str(), path);
+        rc = SPX_E_IO;
+    }
+    if (rc != SPX_OK) remove(tmp.c_str());
+    return rc;
+}
+
+spx_index* spx_index_load_flat(const char* path, int device) {
+    if (!path) {
+        set_error("path is null");
+        return nullptr;
+    }
+    if (select_device(device) != SPX_OK) return nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_error("cannot open %s", path);
+        return nullptr;
+    }
+    SpxFileHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SPXFLAT", 8) != 0 || h.header_bytes != sizeof h) {
+        set_error("%s is not a flat-layout cache of this library", path);
+        fclose(f);
+        return nullptr;
+    }
+    h.layout[sizeof h.layout - 1] = 0;
+    if (strcmp(h.layout, SPX_LAYOUT_VERSION) != 0) {
+        set_error("%s was written by layout '%s', this library is '%s': rebuild the cache", path, h.layout,
+                  SPX_LAYOUT_VERSION);
+        fclose(f);
+        return nullptr;
+    }
+    spx_index* ix = new spx_index();
+    ix->device = device;
+    ix->n = h.n;
+    ix->r = h.r;
+    ix->has_samples = h.has_samples != 0;
+    ix->has_docs = h.has_docs != 0;
+    ix->n_text = h.n_text;
+    ix->view = h.view;
+    ix->device_bytes = h.device_bytes;
+    auto body = [&]() -> int {
+        Staging sg;
+        int rc = sg.init();
+        if (rc != SPX_OK) return rc;
+        void** arr[spx_index::NARR];
+        index_arrays(ix, arr);
+        for (int i = 0; i < spx_index::NARR; ++i) {
+            ix->arr_bytes[i] = h.arr_bytes[i];
+            if (h.arr_bytes[i] == 0) continue;
+            SPX_HIP(hipMalloc(arr[i], h.arr_bytes[i]));
+            if ((rc = read_to_device(f, h.arr_offset[i], *arr[i], h.arr_bytes[i], sg.stage, sg.st, sg.ev)) != SPX_OK)
+                return rc;
+        }
+        SPX_HIP(hipStreamSynchronize(sg.st));
+        bind_view(ix);
+        return init_runtime(ix);
+    };
+    const int rc = body();
+    fclose(f);
+    if (rc != SPX_OK) {
+        spx_index_free(ix);
+        return nullptr;
+    }
+    return ix;
+}
+
+spx_index* spx_index_clone(spx_index* src, int device) {
+    if (!src) {
+        set_error("index is null");
+        return nullptr;
+    }
+    if (select_device(device) != SPX_OK) return nullptr;
+    spx_index* ix = new spx_index();
+    ix->device = device;
+    auto body = [&]() -> int {
+        std::lock_guard<std::mutex> g(src->mu);
+        ix->n = src->n;
+        ix->r = src->r;
+        ix->has_samples = src->has_samples;
+        ix->has_docs = src->has_docs;
+        ix->n_text = src->n_text;
+        ix->view = src->view;
+        ix->device_bytes = src->device_bytes;
+        if (device != src->device) {  // xGMI peer copies when the devices can reach each other
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(src->device, 0);
+            (void)hipGetLastError();  // "already enabled" is fine
+        }
+        void** from[spx_index::NARR];
+        void** to[spx_index::NARR];
+        index_arrays(src, from);
+        index_arrays(ix, to);
+        for (int i = 0; i < spx_index::NARR; ++i) {
+            ix->arr_bytes[i] = src->arr_bytes[i];
+            if (src->arr_bytes[i] == 0) continue;
+            SPX_HIP(hipMalloc(to[i], src->arr_bytes[i]));
+            SPX_HIP(hipMemcpyPeerAsync(*to[i], device, *from[i], src->device, src->arr_bytes[i], nullptr));
+        }
+        SPX_HIP(hipDeviceSynchronize());
+        bind_view(ix);
+        const int rc = init_runtime(ix);
+        memcpy(ix->charhash, src->charhash, sizeof ix->charhash);
+        ix->waves_per_cu = src->waves_per_cu;
+        return rc;
+    };
+    if (body() != SPX_OK) {
+        spx_index_free(ix);
+        return nullptr;
+    }
+    return ix;
+}
+
+int spx_index_describe(const spx_index* ix, char* buf, size_t cap) {
+    if (!ix || !buf || cap == 0) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    const DevIndex& v = ix->view;
+    snprintf(buf, cap,
+             "{\"layout\": \"%s\", \"n\": %llu, \"r\": %llu, \"letters\": %u, \"compact_rows\": %u, "
+             "\"fat_slots\": %llu, \"fat_slots_per_run\": %.4f, \"fat_stride\": %u, \"has_samples\": %d, "
+             "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu}",
+             SPX_LAYOUT_VERSION, (unsigned long long)ix->n, (unsigned long long)ix->r, v.nletters, v.compact,
+             (unsigned long long)v.nfat, (double)v.nfat / (double)(ix->r ? ix->r : 1), v.fat_stride,
+             (int)ix->has_samples, (int)ix->has_docs, (unsigned long long)ix->n_text,
+             (unsigned long long)(ix->device_bytes + ix->n_text));
+    return SPX_OK;
 }
 
 int spx_last_walk_stats(spx_index* ix, spx_walk_stats* out) {

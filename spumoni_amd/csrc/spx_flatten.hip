@@ -8,6 +8,8 @@
 // 10^9-run index is laid out in seconds without touching the host.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -18,6 +20,14 @@ namespace spx {
 namespace {
 
 constexpr int TPB = 256;
+// index arrays start out zeroed: their padding is part of the .spx cache, which has to be a function
+// of the input alone
+#define SPX_ALLOC0(ptr, bytes)                                   \
+    do {                                                         \
+        const size_t nb_ = (bytes);                              \
+        SPX_HIP(hipMalloc((void**)&(ptr), nb_));                 \
+        SPX_HIP(hipMemsetAsync((ptr), 0, nb_, nullptr));         \
+    } while (0)
 inline unsigned nblocks(uint64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 struct DevBuf {  // RAII scratch buffer
@@ -77,7 +87,6 @@ __device__ __forceinline__ uint64_t upper_bound_u64(const uint64_t* a, uint64_t 
 // one thread per byte value: directory range, F[c] and where F[c] lands
 __global__ void k_letters(const uint8_t* Hs, const uint64_t* LFs, const uint64_t* S, uint64_t r,
                           uint64_t n, LetterInfo* out) {
-    __shared__ uint32_t present[256];
     int c = threadIdx.x;
     // lower_bound / upper_bound of c in the sorted head array
     uint64_t lo = 0, hi = r;
@@ -98,20 +107,16 @@ __global__ void k_letters(const uint8_t* Hs, const uint64_t* LFs, const uint64_t
             hi = mid;
     }
     uint64_t qend = lo;
-    present[c] = qend > qbeg ? 1u : 0u;
-    __syncthreads();
-    uint32_t lid = 0;
-    for (int x = 0; x < c; ++x) lid += present[x];
     // F[c] = number of characters smaller than c = LF image of the first c-run start
     uint64_t F = qbeg < r ? LFs[qbeg] : n;
     uint64_t frun = F >= n ? r : upper_bound_u64(S, r, F) - 1;
     LetterInfo li;
-    li.lid = present[c] ? lid : NO_LETTER;
     li.qbeg = (uint32_t)qbeg;
     li.qend = (uint32_t)qend;
     li.frun = (uint32_t)frun;
+    li.bmul = 0;  // the fat table's geometry is decided on the host (flatten_on_device)
     li.foff = F >= n ? 0 : F - S[frun];
-    li.pad_ = 0;
+    li.fbase = 0;
     out[c] = li;
 }
 
@@ -205,30 +210,38 @@ __global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* 
     if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
 
-// block count table: cnt[lid][b] = directory offset of the first c-run with index >= b << s
+// block count table of letter c: cnt[fbase_c + b] = directory position of the first c-run whose
+// block (fat_block(run, bmul_c)) is >= b; qend_c when there is none
 __global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const LetterInfo* letters,
-                           uint64_t r, uint32_t bshift, uint32_t nblk, uint32_t* cnt) {
+                           uint64_t r, uint32_t* cnt) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
     LetterInfo li = letters[Hs[i]];
-    uint32_t* row = cnt + (uint64_t)li.lid * nblk;
-    int64_t b = Qall[i] >> bshift;
-    int64_t pb = i > li.qbeg ? (int64_t)(Qall[i - 1] >> bshift) : -1;
+    uint32_t* row = cnt + li.fbase;
+    const int64_t nblk = (int64_t)fat_block((uint32_t)r, li.bmul) + 2;
+    int64_t b = fat_block(Qall[i], li.bmul);
+    int64_t pb = i > li.qbeg ? (int64_t)fat_block(Qall[i - 1], li.bmul) : -1;
     for (int64_t x = pb + 1; x <= b; ++x) row[x] = (uint32_t)i;
     if (i + 1 == li.qend)
-        for (int64_t x = b + 1; x < (int64_t)nblk; ++x) row[x] = li.qend;
+        for (int64_t x = b + 1; x < nblk; ++x) row[x] = li.qend;
 }
 
-// fat[lid][b] = copy of the jump row of the first c-run at or after block b
-// samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride)
-__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Aux* aux, uint64_t total, char* fat,
-                           uint32_t stride, const uint2* qrange, uint32_t nblk, int force_esc) {
-    // grid-stride: the table can have more than 2^32 slots, a HIP grid cannot have that many threads
-    for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * TPB) {
+// fat slot = digest of the jump row of the first c-run at or after the slot's block;
+// samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride).
+// blockIdx.y walks the letters that occur (lets[]), blockIdx.x strides over the letter's slots.
+__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Aux* aux, const uint32_t* Qall,
+                           const LetterInfo* letters, const uint8_t* lets, uint64_t r, char* fat, uint32_t stride,
+                           int force_esc) {
+    const LetterInfo li = letters[lets[blockIdx.y]];
+    const uint64_t nblk = (uint64_t)fat_block((uint32_t)r, li.bmul) + 2;
+    for (uint64_t b = blockIdx.x * (uint64_t)TPB + threadIdx.x; b < nblk; b += (uint64_t)gridDim.x * TPB) {
+        const uint64_t i = li.fbase + b;
         const uint32_t j = cnt[i];
         char* slot = fat + i * stride;
-        const uint2 qr = qrange[i / nblk];
-        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(dirrows[j], j >= qr.y, j <= qr.x, force_esc != 0);
+        bool single = false;
+        if (j < li.qend && fat_block(Qall[j], li.bmul) == b)
+            single = (j + 1 >= li.qend) || fat_block(Qall[j + 1], li.bmul) > b;
+        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(dirrows[j], j >= li.qend, j <= li.qbeg, force_esc != 0, single);
         if (aux) *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
     }
 }
@@ -351,24 +364,28 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                                T.as<uint64_t>());
 
     // letters
-    SPX_HIP(hipMalloc((void**)&ix->letters, 256 * sizeof(LetterInfo)));
+    SPX_ALLOC0(ix->letters, 256 * sizeof(LetterInfo));
     k_letters<<<1, 256, 0, st>>>(Hs.as<uint8_t>(), LFs.as<uint64_t>(), S.as<uint64_t>(), r, n,
                                   ix->letters);
     std::vector<LetterInfo> hl(256);
     SPX_HIP(hipMemcpyAsync(hl.data(), ix->letters, 256 * sizeof(LetterInfo), hipMemcpyDeviceToHost, st));
     SPX_HIP(hipStreamSynchronize(st));
     uint32_t nletters = 0;
-    for (auto& li : hl)
-        if (li.lid != NO_LETTER) nletters++;
+    std::vector<uint8_t> lets;  // the byte values that occur
+    for (int c = 0; c < 256; ++c)
+        if (hl[c].qend > hl[c].qbeg) {
+            nletters++;
+            lets.push_back((uint8_t)c);
+        }
 
     // rows + jump rows
     const bool docs = d_ds && d_de;
-    SPX_HIP(hipMalloc((void**)&ix->rows, (r + ROW_PAD) * sizeof(Row)));
-    SPX_HIP(hipMalloc((void**)&ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow)));
+    SPX_ALLOC0(ix->rows, (r + ROW_PAD) * sizeof(Row));
+    SPX_ALLOC0(ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow));
     DevBuf dirdocs_tmp;  // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16; packed into aux below
     if (docs) {
         SPX_HIP(dirdocs_tmp.alloc((r + ROW_PAD) * 4));
-        SPX_HIP(hipMalloc((void**)&ix->rundocs, (r + ROW_PAD) * 4));
+        SPX_ALLOC0(ix->rundocs, (r + ROW_PAD) * 4);
     }
     unsigned long long max_len = 0;
     {
@@ -395,46 +412,82 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     (void)hipFree(LFs.p);
     LFs.p = nullptr;
 
-    // Directory block size = how much HBM is traded for speed.  A fat slot answers a jump
-    // outright when no c-run lies between its block's start and the walk's run, so smaller
-    // blocks mean fewer Q / dirrow gathers (measured on C3, same box: 787 / 804 / 867 / 912 M
-    // reads/s at 128 / 64 / 32 / 16 runs per block, for 29 / 45 / 77 / 140 GiB of index).  The
-    // densest table is taken that keeps the whole flat index within the budget: 66 % of the
-    // memory free on the device right now (SPX_INDEX_BUDGET_GB overrides), never coarser than
-    // nletters / 3 runs per block (~96 B per run).
+    // Fat-table geometry = how much HBM is traded for speed.  A fat slot answers a jump outright
+    // when no c-run lies between its block's start and the walk's run, so smaller blocks mean fewer
+    // fat_j / Q / dirrow gathers (measured on C3, same box, uniform blocks: 884 / 975 / 1 051 /
+    // 1 076 M reads/s at 64 / 32 / 16 / 8 runs per block).  Every letter gets its own block size
+    // B_c = K * (r_c / r)^-alpha runs (r_c = runs of the letter): a slot fails with probability
+    // ~ B_c * r_c / r / 2, so for a given number of slots the failures over all letters are fewest
+    // with alpha = 1/2 when every letter is asked for equally often and with alpha = 1 when letters
+    // are asked for as often as they head runs; 0.7 sits between (SPX_FAT_ALPHA overrides).  K is the
+    // smallest value -- the densest tables -- that keeps the whole flat index within the budget:
+    // 66 % of the device's memory (SPX_INDEX_BUDGET_GB overrides) and what is free right now.
     size_t mem_free = 0, mem_total = 0;
     SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
-    double budget = 0.66 * (double)mem_free;
-    if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     const bool has_ms = d_ssa && d_esa;
-    const double per_run = 16 + 32 + 4 + (has_ms ? 24 : 0) + (docs ? 8 : 0);
     const uint32_t fat_row_bytes = sizeof(FatRow);
     const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs) ? (uint32_t)sizeof(Aux) : 0);
-    const double per_slot = fat_stride + 4 /* cnt scratch */;
-    uint32_t bshift = 0;
-    while ((3u << bshift) < nletters && bshift < 16) bshift++;
-    if (const char* e = getenv("SPX_FAT_BSHIFT")) {  // test / experiment knob: force 2^bshift runs per block
-        bshift = (uint32_t)atoi(e) & 31;
-        if (bshift > 20) bshift = 20;
-    } else if (const char* e = getenv("SPX_FAT_DIV")) {  // experiment knob: force nletters / div runs per block
-        const uint32_t div = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 3;
-        bshift = 0;
-        while ((div << bshift) < nletters && bshift < 16) bshift++;
-    } else {
-        while (bshift > 0) {
-            const double slots = (double)nletters * ((double)(r >> (bshift - 1)) + 2);
-            if ((double)r * per_run + slots * per_slot > budget) break;
-            bshift--;
+    const double per_slot = fat_stride + 4 /* fat_j */;
+    // per-run arrays: rows 16 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
+    const double fixed = (double)r * (16 + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));
+    // still to be allocated from the free memory besides the fat table: Q, aux, ss_by_run and the
+    // sample pairs scratch
+    const double to_come = (double)r * (4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 + 16 : 0)) + (64 << 20);
+    double budget = 0.66 * (double)mem_total;
+    if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
+    double fat_bytes = budget - fixed;
+    const double fat_bytes_free = 0.92 * (double)mem_free - to_come;
+    if (fat_bytes > fat_bytes_free) fat_bytes = fat_bytes_free;
+    double max_slots = fat_bytes > 0 ? fat_bytes / per_slot : 0;
+    if (const char* e = getenv("SPX_FAT_SLOTS_PER_RUN")) max_slots = atof(e) * (double)r;  // test / experiment knob
+    double alpha = 0.7;
+    if (const char* e = getenv("SPX_FAT_ALPHA")) alpha = atof(e);
+    int force_bshift = -1;
+    if (const char* e = getenv("SPX_FAT_BSHIFT")) {  // test / experiment knob: 2^b runs per block, every letter
+        force_bshift = atoi(e) & 31;
+        if (force_bshift > 20) force_bshift = 20;
+    }
+    auto geometry = [&](double K, bool commit) -> double {  // slots in all for block sizes K * share^-alpha
+        uint64_t slots = 0;
+        for (uint8_t c : lets) {
+            LetterInfo& li = hl[c];
+            double B = force_bshift >= 0 ? (double)(1u << force_bshift)
+                                         : K * pow((double)(li.qend - li.qbeg) / (double)r, -alpha);
+            if (B < 1.0) B = 1.0;
+            const double m = 4294967296.0 / B;
+            const uint32_t bmul = m >= 4294967295.0 ? 0xffffffffu : (m < 1.0 ? 1u : (uint32_t)m);
+            if (commit) {
+                li.bmul = bmul;
+                li.fbase = slots;
+            }
+            slots += (uint64_t)fat_block((uint32_t)r, bmul) + 2;
+        }
+        return (double)slots;
+    };
+    double K = 1.0;
+    if (force_bshift < 0) {
+        double lo = 1e-6, hi = 4e9;  // slots(K) falls as K grows: smallest K that fits
+        if (geometry(lo, false) <= max_slots) {
+            K = lo;
+        } else {
+            for (int it = 0; it < 80; ++it) {
+                const double mid = sqrt(lo * hi);
+                if (geometry(mid, false) <= max_slots)
+                    hi = mid;
+                else
+                    lo = mid;
+            }
+            K = hi;
         }
     }
-    const uint32_t nblk = (uint32_t)(r >> bshift) + 2;
-    const uint64_t nfat = (uint64_t)nletters * nblk;
+    const uint64_t nfat = (uint64_t)geometry(K, true);
+    SPX_HIP(hipMemcpyAsync(ix->letters, hl.data(), 256 * sizeof(LetterInfo), hipMemcpyHostToDevice, st));
     DevBuf cnt;
     SPX_HIP(cnt.alloc(nfat * 4 + 64));
-    k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, bshift,
-                                            nblk, cnt.as<uint32_t>());
-    SPX_HIP(hipMalloc((void**)&ix->fat, (nfat + 2) * (uint64_t)fat_stride));
-    SPX_HIP(hipMalloc((void**)&ix->q_alloc, (r + 1 + Q_PAD) * 4));
+    SPX_HIP(hipMemsetAsync(cnt.p, 0, nfat * 4 + 64, st));
+    k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, cnt.as<uint32_t>());
+    SPX_ALLOC0(ix->fat, (nfat + 2) * (uint64_t)fat_stride);
+    SPX_ALLOC0(ix->q_alloc, (r + 1 + Q_PAD) * 4);
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
     uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
@@ -443,7 +496,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     DevBuf samples_tmp;
     if (d_ssa && d_esa) {
         SPX_HIP(samples_tmp.alloc((r + 2) * sizeof(SamplePair)));
-        SPX_HIP(hipMalloc((void**)&ix->ss_by_run, (r + 4) * 8));
+        SPX_ALLOC0(ix->ss_by_run, (r + 4) * 8);
         k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, samples_tmp.as<SamplePair>(),
                                                    ix->ss_by_run);
         SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
@@ -452,21 +505,21 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     }
     ix->has_docs = docs;
     if (ix->has_samples || docs) {  // samples + doc words of a directory position in one record
-        SPX_HIP(hipMalloc((void**)&ix->aux, (r + 2) * sizeof(Aux)));
+        SPX_ALLOC0(ix->aux, (r + 2) * sizeof(Aux));
         k_pack_aux<<<nblocks(r + 1), TPB, 0, st>>>(ix->has_samples ? samples_tmp.as<SamplePair>() : nullptr,
                                                     docs ? dirdocs_tmp.as<uint32_t>() : nullptr, r + 1, ix->aux);
         bytes += (r + 2) * sizeof(Aux);
     }
     {
-        std::vector<uint2> qrange(nletters + 1, make_uint2(0, 0));
-        for (auto& li : hl)
-            if (li.lid != NO_LETTER) qrange[li.lid] = make_uint2(li.qbeg, li.qend);
-        DevBuf dq;
-        SPX_HIP(dq.alloc((nletters + 1) * sizeof(uint2)));
-        SPX_HIP(hipMemcpyAsync(dq.p, qrange.data(), (nletters + 1) * sizeof(uint2), hipMemcpyHostToDevice, st));
-        const unsigned fat_grid = nfat / TPB + 1 < (1u << 22) ? (unsigned)(nfat / TPB + 1) : (1u << 22);
-        k_fill_fat<<<fat_grid, TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->aux, nfat, ix->fat, fat_stride,
-                                              dq.as<uint2>(), nblk, getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
+        DevBuf dl;
+        SPX_HIP(dl.alloc(256));
+        SPX_HIP(hipMemcpyAsync(dl.p, lets.data(), lets.size(), hipMemcpyHostToDevice, st));
+        uint64_t most = 0;  // slots of the letter with the most
+        for (uint8_t c : lets) most = std::max<uint64_t>(most, (uint64_t)fat_block((uint32_t)r, hl[c].bmul) + 2);
+        const unsigned gx = most / TPB + 1 < (1u << 20) ? (unsigned)(most / TPB + 1) : (1u << 20);
+        k_fill_fat<<<dim3(gx, nletters), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->aux, Qall.as<uint32_t>(),
+                                                       ix->letters, dl.as<uint8_t>(), r, ix->fat, fat_stride,
+                                                       getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
         SPX_HIP(hipGetLastError());
         SPX_HIP(hipStreamSynchronize(st));
     }
@@ -491,24 +544,24 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 
     // scalars of the initial state (compute_ms_pml.cpp:243, 298, 575, 641-642)
     DevIndex& v = ix->view;
-    v.rows = ix->rows;
-    v.dirrows = ix->dirrows;
-    v.fat = ix->fat;
-    v.Q = ix->q_alloc + 1;
-    v.aux = ix->aux;
-    v.ss_by_run = ix->ss_by_run;
-    v.rundocs = ix->rundocs;
-    v.fat_j = ix->fat_j;
     v.fat_stride = fat_stride;
-    v.letters = ix->letters;
-    v.text = nullptr;
-    v.n_text = 0;
+    ix->n_text = 0;
+    bind_view(ix);
+    ix->arr_bytes[A_ROWS] = (r + ROW_PAD) * sizeof(Row);
+    ix->arr_bytes[A_DIRROWS] = (r + ROW_PAD) * sizeof(JumpRow);
+    ix->arr_bytes[A_FAT] = (nfat + 2) * (uint64_t)fat_stride;
+    ix->arr_bytes[A_FATJ] = nfat * 4 + 64;
+    ix->arr_bytes[A_Q] = (r + 1 + Q_PAD) * 4;
+    ix->arr_bytes[A_AUX] = ix->aux ? (r + 2) * sizeof(Aux) : 0;
+    ix->arr_bytes[A_SSRUN] = ix->ss_by_run ? (r + 4) * 8 : 0;
+    ix->arr_bytes[A_RUNDOCS] = ix->rundocs ? (r + ROW_PAD) * 4 : 0;
+    ix->arr_bytes[A_LETTERS] = 256 * sizeof(LetterInfo);
+    ix->arr_bytes[A_TEXT] = 0;
     v.n = n;
     v.r = (uint32_t)r;
     v.compact = (uint32_t)compact;
     v.nletters = nletters;
-    v.nblk = nblk;
-    v.bshift = bshift;
+    v.nfat = nfat;
     v.init_k = (uint32_t)(r - 1);
     v.init_off = last_len - 1;
     SPX_HIP(hipMemcpy(&v.init_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost));

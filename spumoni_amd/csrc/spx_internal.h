@@ -65,6 +65,9 @@ struct spx_index {
     spx::LetterInfo* letters = nullptr;
     uint8_t* text = nullptr;
     uint64_t n_text = 0;
+    // bytes of every device array above, in the order of spx::index_arrays() (saved / cloned as they are)
+    static constexpr int NARR = 10;
+    uint64_t arr_bytes[NARR] = {};
     spx::DevIndex view{};
     spx::WalkCounters* counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
@@ -91,6 +94,37 @@ struct spx_index {
 };
 
 namespace spx {
+// the device arrays of an index, in a fixed order (cache file / clone)
+enum { A_ROWS, A_DIRROWS, A_FAT, A_FATJ, A_Q, A_AUX, A_SSRUN, A_RUNDOCS, A_LETTERS, A_TEXT };
+inline void index_arrays(spx_index* ix, void*** out) {
+    out[A_ROWS] = (void**)&ix->rows;
+    out[A_DIRROWS] = (void**)&ix->dirrows;
+    out[A_FAT] = (void**)&ix->fat;
+    out[A_FATJ] = (void**)&ix->fat_j;
+    out[A_Q] = (void**)&ix->q_alloc;
+    out[A_AUX] = (void**)&ix->aux;
+    out[A_SSRUN] = (void**)&ix->ss_by_run;
+    out[A_RUNDOCS] = (void**)&ix->rundocs;
+    out[A_LETTERS] = (void**)&ix->letters;
+    out[A_TEXT] = (void**)&ix->text;
+}
+// points the kernel-visible view at the index's arrays (scalars of the view are kept)
+inline void bind_view(spx_index* ix) {
+    DevIndex& v = ix->view;
+    v.rows = ix->rows;
+    v.dirrows = ix->dirrows;
+    v.fat = ix->fat;
+    v.Q = ix->q_alloc ? ix->q_alloc + 1 : nullptr;
+    v.aux = ix->aux;
+    v.ss_by_run = ix->ss_by_run;
+    v.rundocs = ix->rundocs;
+    v.fat_j = ix->fat_j;
+    v.letters = ix->letters;
+    v.text = ix->text;
+    v.n_text = ix->n_text;
+}
+// spx_walk.hip: MS text against the index: text[samples_start[k]] must be the head of run k
+int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream);
 // spx_flatten.hip: builds every device array of `ix` from raw per-run arrays
 // that already live on the device.
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,

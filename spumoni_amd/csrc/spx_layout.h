@@ -24,9 +24,13 @@
 //        Hs       head of the run the successor landing is in
 //        j        position of q in the (letter, run index) order
 //      dirrows[j]            one JumpRow per run, in (letter, run index) order
-//      fat[letter][k >> s]   a 16-byte digest (FatRow) of the JumpRow of the first c-run at
-//                            or after block k >> s: one 16-byte gather answers most jumps
-//                            outright; fat_j[..] is that run's directory position.
+//      fat[fbase_c + blk_c(k)]  a 16-byte digest (FatRow) of the JumpRow of the first c-run at
+//                            or after block blk_c(k) = umulhi(k, bmul_c) of letter c: one 16-byte
+//                            gather answers most jumps outright; fat_j[..] is that run's
+//                            directory position.  Every letter has its own block size
+//                            2^32 / bmul_c (any real number >= 1), chosen at flatten time from the
+//                            letter's share of the runs: dense tables for the letters whose runs
+//                            are dense, coarse ones for the tail.
 //      Q[j]                  run indices in (letter, run) order (4 B), to locate
 //                            the successor when the block holds c-runs before k.
 #pragma once
@@ -37,6 +41,11 @@
 #else
 #define SPX_HD inline
 #endif
+
+// Names the flat layout AND the walk kernels that read it: a .spx cache written by another layout is
+// refused, and measured HBM traffic (profiles/traffic.json) is only quoted for the version it was
+// taken with.  Bump on any change to a record in this file or to the walk's access pattern.
+#define SPX_LAYOUT_VERSION "spx-flat-r02a"
 
 namespace spx {
 
@@ -145,19 +154,24 @@ SPX_HD uint32_t jr_j(const JumpRow& d) { return (uint32_t)d.d3; }
 // first: the slot's run is the letter's first run (a predecessor jump from it is undefined).
 struct alignas(16) FatRow {
     uint64_t w0;  // q[32] | sLFrun[32] << 32
-    uint64_t w1;  // (q - THRrun)[20] | THRoff[16] << 20 | sLFoff[16] << 36 | Hs[8] << 52 |
+    uint64_t w1;  // (q - THRrun)[19] | single << 19 | THRoff[16] << 20 | sLFoff[16] << 36 | Hs[8] << 52 |
                   // psame << 60 | nosucc << 61 | esc << 62 | first << 63
 };
-SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_esc) {
+// single: the slot's run lies in the slot's own block and the letter's NEXT run lies in a later
+// block.  A walk that finds the slot's run before its own run (the slot cannot answer) then knows
+// that the successor is the run of the NEXT slot -- one more 16-byte load, next to the first one,
+// instead of fat_j -> Q -> dirrows.
+constexpr uint64_t FAT_SINGLE = 1ull << 19;
+SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_esc, bool single) {
     const uint32_t q = (uint32_t)f.d0, trun = (uint32_t)(f.d0 >> 32);
     const uint64_t toff = f.d1 & MASK40, soff = f.d2 & MASK40;
     const uint32_t srun = (uint32_t)(f.d1 >> 40) | ((uint32_t)((f.d2 >> 40) & 0xff) << 24);
     const uint64_t dthr = (nosucc || trun > q) ? 0 : (uint64_t)q - trun;
     const bool esc = force_esc || soff >= (1u << 16) ||
-                     (!nosucc && (trun > q || dthr >= (1u << 20) || toff >= (1u << 16)));
+                     (!nosucc && (trun > q || dthr >= (1u << 19) || toff >= (1u << 16)));
     FatRow h;
     h.w0 = (uint64_t)q | ((uint64_t)srun << 32);
-    h.w1 = (dthr & 0xfffff) | ((toff & 0xffff) << 20) | ((soff & 0xffff) << 36) | (((f.d2 >> 49) & 0xff) << 52) |
+    h.w1 = (dthr & 0x7ffff) | (single ? FAT_SINGLE : 0) | ((toff & 0xffff) << 20) | ((soff & 0xffff) << 36) | (((f.d2 >> 49) & 0xff) << 52) |
            (((f.d2 >> 48) & 1) << 60) | ((uint64_t)(nosucc ? 1 : 0) << 61) | ((uint64_t)(esc ? 1 : 0) << 62) |
            ((uint64_t)(first ? 1 : 0) << 63);
     return h;
@@ -165,13 +179,14 @@ SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_
 
 // per byte value c: everything the walk needs that depends only on the letter
 struct alignas(16) LetterInfo {
-    uint32_t lid;    // dense letter id, NO_LETTER if number_of_letter(c) == 0
-    uint32_t qbeg;   // directory range of the letter: Q[qbeg, qend)
+    uint32_t qbeg;   // directory range of the letter: Q[qbeg, qend); empty = number_of_letter(c) == 0
     uint32_t qend;
     uint32_t frun;   // run containing F[c] (r if F[c] == n): landing after an absent letter
+    uint32_t bmul;   // fat block of run k = umulhi(k, bmul): blocks of 2^32 / bmul runs
     uint64_t foff;   // F[c] - S[frun]
-    uint64_t pad_;
+    uint64_t fbase;  // first fat slot of the letter
 };
+SPX_HD uint32_t fat_block(uint32_t k, uint32_t bmul) { return (uint32_t)(((uint64_t)k * bmul) >> 32); }
 
 // Side data of directory position j, everything a jump to run Q[j] (or to the end of run Q[j-1])
 // hands out in MS / doc mode, in 16 bytes:
@@ -200,7 +215,7 @@ struct SamplePair {  // flatten-time temporary: entry j = {samples_start[Q[j]], 
 struct DevIndex {
     const Row* rows;            // r + ROW_PAD rows; row r is the "pos == n" sentinel
     const JumpRow* dirrows;     // r + 1 (+ pad) jump rows, (letter, run) order
-    const char* fat;            // [nletters][nblk] slots of the first c-run at or after the block (see fat_stride)
+    const char* fat;            // slots of the first c-run at or after a block, letter by letter (see fat_stride)
     const uint32_t* Q;          // directory; Q[-1] and Q[r .. r + Q_PAD) are readable
     const Aux* aux;             // r + 1 (+ pad) entries in directory order, or nullptr (PML-only, no docs)
     const uint64_t* ss_by_run;  // samples_start by run index (+ pad) or nullptr
@@ -217,8 +232,7 @@ struct DevIndex {
     uint32_t r;
     uint32_t compact;   // rows use the compact encoding (every run shorter than 2^16)
     uint32_t nletters;  // byte values that occur in the BWT
-    uint32_t nblk;      // blocks per letter in fat (= (r >> bshift) + 2)
-    uint32_t bshift;    // log2(runs per directory block)
+    uint64_t nfat;      // fat slots in all (every letter: fat_block(r, bmul) + 2)
     uint32_t init_k;    // run of position n-1  (= r-1)
     uint64_t init_off;  // (n-1) - S[r-1]
     Row init_row;       // rows[r-1]: every read starts on it, so the walk never gathers it

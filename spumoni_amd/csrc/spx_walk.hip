@@ -17,9 +17,10 @@
 //   P_READ   offsets[rd], offsets[rd+1]   16 B  (next read of this lane)
 //   P_CHARS  32 characters of the read    32 B  (refill, every <= 32 steps)
 //   P_LAND   rows[k0]                     16 B  (run the LF step lands in)
-//   P_FAT    fat[letter][k >> bshift]     16 B  (digest of the jump row of the first c-run
-//                                                at or after the block: usually THE answer)
-//   P_FATJ   fat_j[letter][k >> bshift]    4 B  (only if the digest does not hold the row, or
+//   P_FAT    fat[fbase_c + blk_c(k)]      16 B  (digest of the jump row of the first c-run
+//                                                at or after the block: usually THE answer;
+//                                                the next slot when this one says so)
+//   P_FATJ   fat_j[fbase_c + blk_c(k)]     4 B  (only if the digest does not hold the row, or
 //                                                the block holds c-runs < k: where to go on)
 //   P_QS     Q[j .. j+8)                  32 B  (only if the block holds c-runs < k)
 //   P_DIR    dirrows[j]                   32 B  (only after P_FATJ / P_QS)
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     const char* const fat_b = reinterpret_cast<const char*>(ix.fat);
     const char* const fatj_b = reinterpret_cast<const char*>(ix.fat_j);
     bool fat_found = false;  // P_FAT -> P_FATJ: the slot's run IS the successor (its row did not fit 16 bytes)
+    uint32_t fadd = 0;       // 1: the jump is looking at the slot AFTER its block's (FAT_SINGLE)
     constexpr uint32_t FAT_ROW = sizeof(FatRow);
     const char* const q_b = reinterpret_cast<const char*>(ix.Q);
     const char* const seq_b = reinterpret_cast<const char*>(b.seqs);
@@ -241,10 +243,10 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         if (ph == P_LAND) {
             p0 = rows_b + (uint64_t)k0 * sizeof(Row);
         } else if (ph == P_FAT) {
-            fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
+            fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
             p0 = fat_b + fidx * ix.fat_stride;
         } else if (ph == P_FATJ) {
-            fidx = (uint64_t)s_let[c].lid * ix.nblk + (k >> ix.bshift);
+            fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
             p0 = fatj_b + ((fidx * 4) & ~15ull);  // the aligned 16 bytes that hold fat_j[fidx]
         } else if (ph == P_DIR) {
             p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
@@ -314,12 +316,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 // below (j is not known and not needed: only its place in [qbeg, qend] matters)
                 const uint64_t w0 = g0, w1 = g1;
                 const uint32_t srun = (uint32_t)(w0 >> 32);
-                g0 = (uint64_t)hq | ((uint64_t)(hq - (uint32_t)(w1 & 0xfffff)) << 32);
+                g0 = (uint64_t)hq | ((uint64_t)(hq - (uint32_t)(w1 & 0x7ffff)) << 32);
                 g1 = ((w1 >> 20) & 0xffff) | ((uint64_t)(srun & 0xffffff) << 40);
                 g2 = ((w1 >> 36) & 0xffff) | ((uint64_t)(srun >> 24) << 40) | (((w1 >> 60) & 1) << 48) |
                      (((w1 >> 52) & 0xff) << 49);
                 jdir = nosucc ? qend : (((w1 >> 63) & 1) ? qbeg : qbeg + 1);
                 do_decide = true;
+            } else if (!fat_found && (g1 & FAT_SINGLE) && fadd == 0) {
+                fadd = 1;  // the letter's next run lies past this block: it is the next slot's run
             } else {
                 ph = P_FATJ;  // need the slot's directory position: full row, or a scan from there
             }
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 const uint32_t wi = (uint32_t)(g - wbase);
                 c = WIN_CHAR(wi);
                 const LetterInfo li = s_let[c];
-                if (li.lid == NO_LETTER) {  // number_of_letter(c) == 0   (:249)
+                if (li.qbeg == li.qend) {  // number_of_letter(c) == 0   (:249)
                     length = 0;
                     if (MODE == SPX_MODE_MS) {
                         sample = 0;                 // :581
@@ -513,6 +517,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     quirk = (k < R && H_k == c);
                     qbeg = li.qbeg;
                     qend = li.qend;
+                    fadd = 0;
                     ph = P_FAT;
                 }
             }
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                         const uint32_t wi = (uint32_t)(g - wbase);
                         const uint32_t cn = WIN_CHAR(wi);
                         const LetterInfo li = s_let[cn];
-                        if (li.lid != NO_LETTER && cn != Hland && k0 < R) {
+                        if (li.qbeg != li.qend && cn != Hland && k0 < R) {
                             k = k0;
                             off = offp;
                             H_k = Hland;
@@ -603,6 +608,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                             quirk = false;
                             qbeg = li.qbeg;
                             qend = li.qend;
+                            fadd = 0;
                             n_jumps++;
                             ph = P_FAT;
                         }
@@ -700,7 +706,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     for (uint64_t i = 0; i < m; ++i) {
         // pointers are fetched two at a time (one aligned 16-byte load per pair)
         const uint64_t gi = base + i;
-        if ((gi & 1) == 0 || i == 0) {
+        if ((gi & 1) == 0 && i + 1 == m) {
+            pc0 = b.out_pointers[gi];  // the read's last pointer at an even index: its pair would lie past the buffer
+        } else if ((gi & 1) == 0 || i == 0) {
             const ulonglong2 pp = *reinterpret_cast<const ulonglong2*>(b.out_pointers + (gi & ~1ull));
             pc0 = pp.x;
             pc1 = pp.y;
@@ -754,6 +762,19 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
         }
         b.out_class[rd] = spx_class{sum_max, above, below};
     }
+}
+
+// spx_index_set_text: the text against the index.  The BWT character at the start of run k is the
+// text character in front of that suffix, i.e. text[samples_start[k]] (the stored sample is
+// SA - 1, compute_ms_pml.cpp:433; n - 1 marks the terminator, which the text does not hold).
+__global__ void k_text_check(const DevIndex ix, unsigned long long* bad) {
+    const uint64_t k = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (k >= ix.r) return;
+    const Row row = ix.rows[k];
+    const uint32_t H = ix.compact ? crow_H(row) : row_H(row);
+    const uint64_t s = ix.ss_by_run[k];
+    const bool ok = s < ix.n_text ? ix.text[s] == H : (s == ix.n - 1 && H <= 1);
+    if (!ok) atomicAdd(bad, 1ull);
 }
 
 template <int MODE, bool DOC, bool COMPACT, bool NARROW>
@@ -847,6 +868,13 @@ int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_c
 #undef SPX_CASE
     }
     return SPX_E_ARG;
+}
+
+int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream) {
+    const unsigned grid = (unsigned)((ix->r + WALK_TPB - 1) / WALK_TPB);
+    k_text_check<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, d_bad);
+    SPX_HIP(hipGetLastError());
+    return SPX_OK;
 }
 
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream) {

@@ -1,0 +1,100 @@
+"""-m gpu: the flat-layout cache (.spx), index replication, and the text-against-index check.
+
+pml_t / ms_t deserialise their index on every run (compute_ms_pml.cpp:700-721, 755-786); here the
+flat arrays are written once and brought back by plain copies, and an index is replicated to the
+other devices by a device-to-device copy instead of being flattened again."""
+import filecmp
+
+import numpy as np
+import pytest
+import torch
+
+from spumoni_amd import capi, synth
+from tests import cases
+from tests.test_gpu_parity import _compare_all
+
+pytestmark = pytest.mark.gpu
+
+DNA = list(b"ACGT")
+
+
+@pytest.mark.parametrize("kind", ["real_ms_doc", "statistical_pml", "wide_rows"])
+def test_cache_round_trip_is_byte_identical_and_queries_agree(oracle_mod, tmp_path, kind, monkeypatch):
+    rng = np.random.default_rng(5)
+    if kind == "wide_rows":
+        monkeypatch.setenv("SPX_ROWS_WIDE", "1")
+    if kind == "statistical_pml":
+        raw = synth.statistical_rlbwt(40_000, 60, 4.0, seed=3, device="cuda", zipf=1.0)
+        text = None
+        seqs, offs = synth.simulate_reads(raw, 2000, 50, seed=4)
+        seqs, offs = seqs.cpu().numpy(), offs.cpu().numpy()
+    else:
+        raw, text = cases.real_case(31, 8000, DNA, ndocs=4)
+        seqs, offs = cases.reads_mixed(rng, text, DNA, 300, 150, [ord("N")])
+    fresh = capi.Index.from_raw(raw, 0)
+    a, b = str(tmp_path / "a.spx"), str(tmp_path / "b.spx")
+    fresh.save(a)
+    loaded = capi.Index.load_flat(a, 0)
+    assert (loaded.n, loaded.r) == (fresh.n, fresh.r)
+    assert loaded.describe() == fresh.describe()
+    loaded.save(b)
+    assert filecmp.cmp(a, b, shallow=False), "cache of a loaded index differs from the cache of the fresh one"
+    # a second flatten of the same input writes the same bytes (the layout is a function of the input)
+    again = capi.Index.from_raw(raw, 0)
+    again.save(b)
+    assert filecmp.cmp(a, b, shallow=False), "flattening is not deterministic"
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=loaded)
+
+
+def test_clone_answers_like_the_original(oracle_mod):
+    raw, text = cases.real_case(32, 6000, [3, 4, 90, 128, 200, 255], ndocs=3)
+    rng = np.random.default_rng(6)
+    seqs, offs = cases.reads_mixed(rng, text, [3, 4, 90, 128, 200, 255], 200, 120, [2])
+    src = capi.Index.from_raw(raw, 0)
+    dup = src.clone(0)
+    assert dup.describe() == src.describe()
+    src.close()  # the clone owns its arrays
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=dup)
+
+
+def test_cache_of_another_layout_is_refused(tmp_path):
+    raw = synth.statistical_rlbwt(500, 5, 3.0, seed=1)
+    ix = capi.Index.from_raw(raw, 0)
+    p = str(tmp_path / "x.spx")
+    ix.save(p)
+    blob = bytearray(open(p, "rb").read())
+    blob[8:12] = b"old!"  # the layout tag follows the 8-byte magic
+    open(p, "wb").write(bytes(blob))
+    with pytest.raises(capi.SpxError, match="rebuild the cache"):
+        capi.Index.load_flat(p, 0)
+    open(p, "wb").write(b"not a cache")
+    with pytest.raises(capi.SpxError):
+        capi.Index.load_flat(p, 0)
+    with pytest.raises(capi.SpxError):
+        capi.Index.load_flat(str(tmp_path / "missing.spx"), 0)
+
+
+def test_text_that_is_not_the_indexed_text_is_refused():
+    """a wrong SPUMONI_TEXT silently gave wrong .lengths.  The text is now checked against
+    the index: its length, and text[samples_start[k]] == head of run k for every run."""
+    raw, text = cases.real_case(33, 5000, DNA, ndocs=2)
+    t = torch.from_numpy(text.copy())
+    raw.text = None
+    ix = capi.Index.from_raw(raw, 0)
+    ix.set_text(t)  # the right text passes
+    with pytest.raises(capi.SpxError, match="characters"):
+        ix.set_text(t[:-1])  # wrong length
+    wrong = t.clone()
+    wrong[1000:1100] = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[(np.arange(100) % 4)].copy())
+    if not torch.equal(wrong, t):
+        with pytest.raises(capi.SpxError, match="disagrees"):
+            ix.set_text(wrong)
+    rev = torch.flip(t, [0])  # same length, same letters, another text (e.g. missing reverse complements)
+    with pytest.raises(capi.SpxError, match="disagrees"):
+        ix.set_text(rev)
+    with pytest.raises(capi.SpxError):  # after a refusal the index has no text
+        ix.query_host(capi.SPX_MODE_MS, text[:50], np.array([0, 50]))
+    ix.set_text(rev, unchecked=True)  # explicit opt-out (synthetic indexes)
+    ix.set_text(t)
+    got = ix.query_host(capi.SPX_MODE_MS, text[100:180], np.array([0, 80]))
+    assert got["lengths"][0] >= 80 - 0  # a substring of the text matches to its end

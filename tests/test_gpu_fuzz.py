@@ -1,6 +1,6 @@
 """-m gpu: many small random indexes x random layout knobs, all four query variants against the
 oracle.  Cheap insurance for the paths that depend on the index's shape: compact / general rows,
-16-byte fat digests and their escape, every fat block size, long runs, rare letters, bytes >= 128,
+16-byte fat digests and their escape, every fat block size (uniform and per letter), long runs, rare letters, bytes >= 128,
 consistent and inconsistent thresholds."""
 import numpy as np
 import pytest
@@ -37,8 +37,12 @@ def test_random_index_shapes(gpu, oracle_mod, seed, monkeypatch):
     if seed % 4 == 2:  # thresholds anywhere: every step still defined upstream (Appendix C1 general path)
         nz = raw.thr > 0
         raw.thr = torch.where(nz, torch.from_numpy(rng.integers(1, raw.n + 1, size=raw.r)), raw.thr)
-    if rng.random() < 0.5:
+    knob = int(rng.integers(0, 3))
+    if knob == 0:  # one block size for every letter
         monkeypatch.setenv("SPX_FAT_BSHIFT", str(int(rng.integers(0, 8))))
+    elif knob == 1:  # per-letter block sizes: table density and the exponent of the letters' run shares
+        monkeypatch.setenv("SPX_FAT_SLOTS_PER_RUN", str(float(rng.choice([0.02, 0.3, 1.5, 6.0, 40.0]))))
+        monkeypatch.setenv("SPX_FAT_ALPHA", str(float(rng.choice([0.0, 0.5, 0.7, 1.0]))))
     if rng.random() < 0.25:
         monkeypatch.setenv("SPX_FAT_ALL_ESC", "1")
     if rng.random() < 0.25:

@@ -258,13 +258,21 @@ def test_limits_are_enforced(gpu):
         ix.query_host(capi.SPX_MODE_PML, rd, offs, want_docs=True)
 
 
-@pytest.mark.parametrize("bshift,wide_rows,all_esc", [(0, 0, 0), (2, 1, 0), (5, 0, 0), (9, 1, 0), (0, 0, 1), (3, 1, 1)])
+@pytest.mark.parametrize("bshift,wide_rows,all_esc", [(0, 0, 0), (2, 1, 0), (5, 0, 0), (9, 1, 0), (0, 0, 1), (3, 1, 1),
+                                                      ("0.05:1.0", 0, 0), ("0.8:0.7", 1, 0), ("3:0.5", 0, 1),
+                                                      ("12:0.0", 0, 0)])
 def test_every_directory_block_size(gpu, oracle_mod, bshift, wide_rows, all_esc, monkeypatch):
-    """The fat-table block size is chosen from the free memory; force it from 1 to 512 runs per
-    block so that the direct answer, the one-window and the multi-window directory scans all run
-    (with both row encodings); all_esc marks every 16-byte fat digest as not holding its row, so
-    that every jump goes through fat_j and the full JumpRow."""
-    monkeypatch.setenv("SPX_FAT_BSHIFT", str(bshift))
+    """The fat table's geometry is chosen from the free memory; force it -- one block size for all
+    letters from 1 to 512 runs, or per-letter block sizes at a given table density ("slots per
+    run:alpha") -- so that the direct answer, the next-slot answer, the one-window and the
+    multi-window directory scans all run (with both row encodings); all_esc marks every 16-byte fat
+    digest as not holding its row, so that every jump goes through fat_j and the full JumpRow."""
+    if isinstance(bshift, str):
+        spr, alpha = bshift.split(":")
+        monkeypatch.setenv("SPX_FAT_SLOTS_PER_RUN", spr)
+        monkeypatch.setenv("SPX_FAT_ALPHA", alpha)
+    else:
+        monkeypatch.setenv("SPX_FAT_BSHIFT", str(bshift))
     if all_esc:
         monkeypatch.setenv("SPX_FAT_ALL_ESC", "1")
     if wide_rows:
