@@ -113,6 +113,8 @@ void spx_index_free(spx_index* ix) {
     }
     for (auto& sc : ix->scratch)
         if (sc.p) (void)hipFree(sc.p);
+    for (auto& sc : ix->chunk_scr)
+        if (sc.p) (void)hipFree(sc.p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
@@ -343,6 +345,14 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->force_lanes_per_wave = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "chunk_mode")) {  // long-read chunking: 0 automatic, 1 never, 2 always
+        ix->chunk_mode = (int)value;
+        return SPX_OK;
+    }
+    if (!strcmp(key, "chunk_shift")) {  // log2 of the chunk size (0 = automatic)
+        ix->chunk_shift = (int)value;
+        return SPX_OK;
+    }
     if (!strcmp(key, "digest_kernel")) {
         ix->force_digest_kernel = (int)value;
         return SPX_OK;
@@ -519,8 +529,9 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     a.narrow = narrow ? 1 : 0;
     SPX_HIP(hipEventRecord(ix->ev0, st));
     if (nreads > 0) {
-        rc = launch_walk(ix, mode, a, total_chars, st);
-        if (rc != SPX_OK) return rc;
+        bool chunked = false;
+        if ((rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
+        if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st)) != SPX_OK) return rc;
     }
     SPX_HIP(hipEventRecord(ix->ev1, st));
     if (mode == SPX_MODE_MS && d_out_lengths && nreads > 0) {

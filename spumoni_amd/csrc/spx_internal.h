@@ -31,6 +31,56 @@ struct WalkCounters {
     unsigned long long pad_;
 };
 
+// ---- long reads: exact speculative chunking (spx_walk.hip) -----------------------
+// The walk of a read is one dependent chain; a batch with fewer reads than the chip has lanes is
+// latency-bound.  Such a batch is cut into chunks -- a read's intersection with an aligned block of
+// CHUNK characters of the concatenated input -- and
+//   pass 1  every chunk is walked from the default state (pos = n - 1): right for a read's last
+//           chunk, speculative for the others;
+//   pass 2  for every other chunk, the walk that ended the chunk above it (its recorded end state)
+//           is carried on into the chunk, overwriting the speculative results, until its position
+//           equals the position the speculative walk recorded at the same character (checkpoints):
+//           from there on the two walks are the same walk;
+//   pass 3  per read, top down: `length` / `sample` are counters that the walk only adds to until
+//           the next jump resets them, so what is left of a wrong start value is a constant
+//           offset (a stale value, for the document id) up to the first reset below each seam:
+//           patched from the recorded values;
+//   then the bin classifier runs over the finished lengths, and a read in which some seam did
+//   not close inside its chunk is simply walked again the plain way.
+struct ChunkDesc {     // 16 B
+    uint64_t gend;     // index (in the concatenated input) one past the chunk's last character
+    uint32_t len;      // characters
+    uint32_t rd;       // read
+};
+struct WalkState {     // 32 B: what a walk carries from one character to the next
+    uint32_t k0;       // landing target of the last step: run ...
+    uint32_t length;   // PML length counter
+    uint64_t offp;     // ... and offset (OFF_END: last position of the run)
+    uint64_t sample;   // MS pointer counter
+    uint32_t doc;      // current document id
+    uint32_t flags;    // bit 0: a reset happened since the state's owner started
+};
+struct SeamRec {       // 64 B, one per chunk that is not its read's last: where and how pass 2 ended
+    uint64_t t;        // pass 2 stopped with the results of [t, chunk end) written; t == chunk start: never met
+    uint32_t met;      // 1: positions met at t; 0: ran to the chunk's start
+    uint32_t reset_above;  // pass 2 saw a reset between the chunk's end and t
+    WalkState ext;     // pass 2's counters at t
+    uint32_t spec_length, spec_doc;
+    uint64_t spec_sample;  // the speculative walk's counters at t
+};
+constexpr uint32_t CKPT_SHIFT = 4;  // a checkpoint every 16 characters
+
+struct ChunkArgs {
+    const ChunkDesc* desc;       // chunks, a read's chunks consecutive, last chunk of a read first... no: ascending
+    const uint64_t* nchunks;     // device counter
+    WalkState* ends;             // per chunk: state after the chunk's first (lowest) character
+    WalkState* ckpt;             // per 16 characters of the input: state before character 16 * i - 1
+    SeamRec* seams;              // per chunk
+    uint8_t* flags;              // per character: bit 0 length / sample were reset, bit 1 doc was set
+    uint32_t* read_fail;         // per read: a seam did not close
+    const uint64_t* chunk_start; // per read: first chunk
+};
+
 struct BatchArgs {
     const uint8_t* seqs;   // readable for round_up(total_chars, 4) + 32 bytes
     const uint64_t* offs;
@@ -46,6 +96,8 @@ struct BatchArgs {
     WalkCounters* counters;
     uint32_t lanes_per_wave;  // active lanes per wavefront (64 unless the batch is small)
     uint32_t narrow;          // out_lengths / out_docs point to uint16_t arrays (reads < 65536 characters)
+    ChunkArgs ch;             // chunked walks only
+    const uint32_t* only_flagged;  // plain walk: skip the reads whose flag is 0 (fallback after chunking)
 };
 
 }  // namespace spx
@@ -90,7 +142,9 @@ struct spx_index {
     struct Scratch {
         void* p = nullptr;
         size_t cap = 0;
-    } scratch[8];
+    } scratch[8], chunk_scr[8];  // host-buffer queries; chunked walks (under mu)
+    int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
+    int chunk_shift = 0;  // "chunk_shift" option: log2 of the chunk size (0 = automatic)
 };
 
 namespace spx {
@@ -123,6 +177,20 @@ inline void bind_view(spx_index* ix) {
     v.text = ix->text;
     v.n_text = ix->n_text;
 }
+// grow-only device scratch of the chunked walk (callers hold ix->mu)
+inline int chunk_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
+    spx_index::Scratch& sc = ix->chunk_scr[slot];
+    if (sc.cap < bytes) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr;
+        sc.cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        SPX_HIP(hipMalloc(&sc.p, want));
+        sc.cap = want;
+    }
+    *out = sc.p;
+    return SPX_OK;
+}
 // spx_walk.hip: MS text against the index: text[samples_start[k]] must be the head of run k
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream);
 // spx_flatten.hip: builds every device array of `ix` from raw per-run arrays
@@ -134,6 +202,10 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
                 hipStream_t stream);
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream);
+// long-read batches: the chunked walk (returns SPX_OK and sets *done = false when the batch does not
+// qualify and the plain walk should run)
+int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
+                        bool* done);
 // spx_digest.hip: d_out_offs gets nreads + 1 offsets, d_out the digested reads (capacity is the
 // caller's business: spx_digest_capacity)
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,

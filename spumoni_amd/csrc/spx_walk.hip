@@ -30,6 +30,8 @@
 // unique, all 64 lanes of a wave always have their gather in flight together
 // no matter which phase each is in: no lane waits for another lane's longer
 // step, and no phase serialises behind another phase's s_waitcnt.
+#include <hipcub/hipcub.hpp>
+
 #include <type_traits>
 
 #include "spx_internal.h"
@@ -48,7 +50,9 @@ enum : uint32_t {
     P_AUX = 6,
     P_SAMP = 7,
     P_FATJ = 8,
-    P_DONE = 9
+    P_DONE = 9,
+    P_START = 10,  // chunked walk, pass 2: the end state of the chunk above
+    P_CKPT = 11    // chunked walk, pass 2: the speculative walk's state at a checkpoint
 };
 
 constexpr int WALK_TPB = 256;
@@ -153,9 +157,13 @@ __device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t val
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
 // ---------------------------------------------------------------------------
-template <int MODE, bool DOC, bool COMPACT, bool NARROW>
+// CHUNK: 0 = reads; 1 = pass 1 of the chunked walk (every chunk from the default state, checkpoints
+// and end states recorded); 2 = pass 2 (a chunk entered with the end state of the chunk above,
+// until the walk meets the recorded one) -- spx_internal.h
+template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
     constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
+    const uint64_t nitems = CHUNK ? *b.ch.nchunks : b.nreads;  // work items: reads, or chunks
     __shared__ LetterInfo s_let[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) s_let[t] = ix.letters[t];
     __syncthreads();
@@ -171,7 +179,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     const char* const seq_b = reinterpret_cast<const char*>(b.seqs);
     const char* const off_b = reinterpret_cast<const char*>(b.offs);
     const uint32_t R = ix.r;
-    const bool want_class = (MODE == SPX_MODE_PML) && b.out_class != nullptr;
+    const bool want_class = (CHUNK == 0) && (MODE == SPX_MODE_PML) && b.out_class != nullptr;
     // lanes_per_wave < 64 spreads a small batch over more wavefronts (see launch_lanes)
     const uint32_t lpw = b.lanes_per_wave;
     const uint64_t nlanes = (((uint64_t)gridDim.x * blockDim.x) >> 6) * lpw;
@@ -211,7 +219,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // statistics
     uint32_t n_steps = 0, n_jumps = 0, n_pred = 0, n_rows = 0, n_dir = 0, n_err = 0;
 
-    if (rd >= b.nreads || (threadIdx.x & 63) >= lpw) ph = P_DONE;
+    // chunked walks
+    uint32_t rflag = 0;      // what the current step reset: bit 0 length / sample, bit 1 document id
+    uint64_t fb = 0;         // pass 1: flags of the aligned group of 8 characters, a byte each
+    uint32_t item_rd = 0, item_flags = 0, seen = 0, ph_after = P_LAND;
+    if (rd >= nitems || (threadIdx.x & 63) >= lpw) ph = P_DONE;
 #define STAND_ON(row)                                \
     do {                                             \
         if (COMPACT) {                               \
@@ -255,13 +267,17 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else if (ph == P_CHARS) {
             p0 = seq_b + wbase;
         } else if (ph == P_READ) {
-            p0 = off_b + rd * 8;
+            p0 = CHUNK ? reinterpret_cast<const char*>(b.ch.desc + rd) : off_b + rd * 8;
+        } else if (CHUNK == 2 && ph == P_START) {
+            p0 = reinterpret_cast<const char*>(b.ch.ends + rd + 1);  // the chunk above is the next one
+        } else if (CHUNK == 2 && ph == P_CKPT) {
+            p0 = reinterpret_cast<const char*>(b.ch.ckpt + ((base + x) >> CKPT_SHIFT));
         } else if (MODE == SPX_MODE_MS && ph == P_SAMP) {
             p0 = reinterpret_cast<const char*>(ix.ss_by_run + k);
         } else {
             p0 = rows_b;
         }
-        const bool wide = (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS);
+        const bool wide = (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS) | (CHUNK == 2 && (ph == P_START || ph == P_CKPT));
         const V16 ga = *reinterpret_cast<const V16*>(p0);
         V16 gb{0, 0, 0, 0};
         if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
@@ -366,13 +382,53 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             s_win[6 * WALK_TPB + threadIdx.x] = (uint32_t)g3;
             s_win[7 * WALK_TPB + threadIdx.x] = (uint32_t)(g3 >> 32);
             do_step = true;  // only entered from a landed state
-        } else if (ph == P_READ) {
-            base = g0;
-            m = (uint32_t)(g1 - g0);
-            if (m == 0) {
-                if (want_class) b.out_class[rd] = spx_class{0, 0, 0};
+        } else if (CHUNK == 2 && ph == P_START) {
+            // the walk that ended the chunk above goes on into this one
+            k0 = (uint32_t)g0;
+            length = (uint32_t)(g0 >> 32);
+            offp = (g1 == OFF_END) ? OFF_LAST : (offs_t)g1;
+            sample = g2;
+            doc = (uint32_t)g3;
+            seen = 0;
+            wbase = ~0ull;  // no characters yet: the first step fetches its window
+            ph = P_LAND;
+        } else if (CHUNK == 2 && ph == P_CKPT) {
+            n_dir++;
+            const uint64_t my_off = (offp == OFF_LAST) ? OFF_END : (uint64_t)offp;
+            if ((uint32_t)g0 == k0 && g1 == my_off) {
+                // same position before the same character: from here on the speculative walk IS this walk
+                SeamRec sr;
+                sr.t = base + x;
+                sr.met = 1;
+                sr.reset_above = seen;
+                sr.ext = WalkState{k0, length, my_off, sample, doc, seen};
+                sr.spec_length = (uint32_t)(g0 >> 32);
+                sr.spec_doc = (uint32_t)g3;
+                sr.spec_sample = g2;
+                b.ch.seams[rd] = sr;
                 rd += nlanes;
-                if (rd >= b.nreads) ph = P_DONE;
+                ph = rd < nitems ? P_READ : P_DONE;
+            } else {
+                ph = ph_after;
+            }
+        } else if (ph == P_READ) {
+            if (CHUNK) {  // ChunkDesc: gend, len | top << 31 | bottom << 30, read
+                item_flags = (uint32_t)g1 >> 30;
+                item_rd = (uint32_t)(g1 >> 32);
+                m = (uint32_t)g1 & 0x3fffffffu;
+                base = g0 - m;
+            } else {
+                base = g0;
+                m = (uint32_t)(g1 - g0);
+            }
+            if (CHUNK == 0 && b.only_flagged != nullptr && b.only_flagged[rd] == 0) m = 0;  // not this pass's read
+            if (CHUNK == 2 && (item_flags & 2)) {  // a read's last chunk was right from the start
+                rd += nlanes;
+                if (rd >= nitems) ph = P_DONE;
+            } else if (m == 0) {
+                if (want_class && b.only_flagged == nullptr) b.out_class[rd] = spx_class{0, 0, 0};
+                rd += nlanes;
+                if (rd >= nitems) ph = P_DONE;
             } else {
                 if (NARROW && m >= 65536) n_err++;  // 16-bit outputs cannot hold this read's values
                 x = m;
@@ -389,6 +445,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     wbase = end4 >= 32 ? end4 - 32 : 0;
                 }
                 ob_lo = ob_hi = db_lo = db_hi = 0;
+                fb = 0;
+                seen = 0;
+                if (CHUNK == 2) ph = P_START;
                 if (want_class) {
                     const uint32_t w = (uint32_t)b.bin_width;
                     // m / w without a divide: bin_magic = floor(2^64 / w) + 1 (exact for m < 2^32)
@@ -398,18 +457,20 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     bin_max = above = below = 0;
                     sum_max = 0;
                 }
-                ph = P_CHARS;
+                if (CHUNK != 2) ph = P_CHARS;
             }
         } else if (ph == P_AUX) {
             // only the inconsistent-threshold case of Appendix C1 comes here: side data of the
             // directory position AFTER run k (samples_last[k] / end_runs_doc[k])
             if (MODE == SPX_MODE_MS) sample = sp.se;
             if (DOC) doc = dd >> 16;
+            rflag = 3;
             do_emit = true;
         } else {  // P_SAMP: byte >= 128 sitting on its own run (Appendix C1): stays there
             if (MODE == SPX_MODE_MS) sample = g0;  // samples_start[run of pos]
             if (DOC) doc = dd & 0xffff;            // start_runs_doc[run of pos]
             LF_TARGET();
+            rflag = 3;
             do_emit = true;
         }
 
@@ -471,6 +532,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else {
                 if (MODE == SPX_MODE_MS) sample = aux_take ? sp.se : sp.ss;   // :601 / :611
                 if (DOC) doc = aux_take ? (dd >> 16) : (dd & 0xffff);          // :317 / :327
+                rflag = 3;
                 do_emit = true;
             }
         }
@@ -494,11 +556,13 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     }
                     k0 = li.frun;  // LF(pos, c) = F[c] + 0
                     offp = (offs_t)li.foff;
+                    rflag = MODE == SPX_MODE_MS ? 3 : 1;  // PML keeps its document id over an absent letter
                     do_emit = true;
                 } else if (k < R && H_k == c && c < 128) {  // pos < n && bwt[pos] == c   (:250)
                     length++;
                     sample--;  // :582 (wraps, Appendix C3)
                     LF_TARGET();
+                    rflag = 0;
                     do_emit = true;
                 } else if (k < R && H_k == c && thr_ok_k) {
                     // byte >= 128 equal to the head (signed-char quirk, Appendix C1): the jump
@@ -510,6 +574,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                         ph = P_SAMP;  // sample = samples_start[k], doc = start_runs_doc[k]
                     } else {
                         LF_TARGET();
+                        rflag = 3;
                         do_emit = true;
                     }
                 } else {
@@ -526,7 +591,44 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         if (do_emit) {
             const uint32_t xi = x - 1;
             const uint64_t gi = base + xi;
-            if (MODE == SPX_MODE_PML) {
+            if (CHUNK) {
+                // which counters this step reset: what pass 3 needs to know where a wrong start value ends
+                seen |= rflag;
+                if (CHUNK == 2) {
+                    b.ch.flags[gi] = (uint8_t)rflag;
+                } else {
+                    const uint32_t slot = (uint32_t)gi & 7;
+                    fb |= (uint64_t)rflag << (slot * 8);
+                    if (slot == 0 || xi == 0) {
+                        const uint64_t g8 = gi & ~7ull;
+                        if (g8 >= base && g8 + 7 < base + m) {
+                            *reinterpret_cast<uint64_t*>(b.ch.flags + g8) = fb;
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+                                if (g8 + t >= gi && g8 + t < base + m) b.ch.flags[g8 + t] = (uint8_t)(fb >> (t * 8));
+                        }
+                        fb = 0;
+                    }
+                }
+            }
+            if (CHUNK == 2) {
+                // pass 2 writes over the speculative results one value at a time (a few steps per chunk)
+                if (MODE == SPX_MODE_PML) {
+                    if (NARROW)
+                        reinterpret_cast<uint16_t*>(b.out_lengths)[gi] = (uint16_t)length;
+                    else
+                        b.out_lengths[gi] = length;
+                } else {
+                    b.out_pointers[gi] = sample;
+                }
+                if (DOC) {
+                    if (NARROW)
+                        reinterpret_cast<uint16_t*>(b.out_docs)[gi] = (uint16_t)doc;
+                    else
+                        b.out_docs[gi] = doc;
+                }
+            } else if (MODE == SPX_MODE_PML) {
                 // lengths[m-i-1] = length   (:281)
                 if (NARROW)
                     stage8n(ob_lo, ob_hi, length, reinterpret_cast<uint16_t*>(b.out_lengths), gi, xi, base, m);
@@ -555,7 +657,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     }
                 }
             }
-            if (DOC) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
+            if (DOC && CHUNK != 2) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
                 if (NARROW)
                     stage8n(db_lo, db_hi, doc, reinterpret_cast<uint16_t*>(b.out_docs), gi, xi, base, m);
                 else if (m < 65536)
@@ -586,8 +688,24 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     sum_max += bin_max;
                     b.out_class[rd] = spx_class{sum_max, above, below};
                 }
+                if (CHUNK == 1)  // what a walk entering the chunk below starts from
+                    b.ch.ends[rd] = WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
+                if (CHUNK == 2) {
+                    // reached the chunk's first character without meeting the speculative walk: fine for a
+                    // read's first chunk (the read is done), otherwise the read is walked again plainly
+                    SeamRec sr;
+                    sr.t = base;
+                    sr.met = 0;
+                    sr.reset_above = seen;
+                    sr.ext = WalkState{k0, length, 0, sample, doc, seen};
+                    sr.spec_length = 0;
+                    sr.spec_doc = 0;
+                    sr.spec_sample = 0;
+                    b.ch.seams[rd] = sr;
+                    if (!(item_flags & 1)) b.ch.read_fail[item_rd] = 1;
+                }
                 rd += nlanes;
-                ph = rd < b.nreads ? P_READ : P_DONE;
+                ph = rd < nitems ? P_READ : P_DONE;
             } else {
                 ph = P_LAND;
                 if (peek) {
@@ -616,6 +734,16 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 }
             }
             peek = false;
+            if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
+                // checkpoint: the state before character base + x - 1
+                if (CHUNK == 1) {
+                    b.ch.ckpt[(base + x) >> CKPT_SHIFT] =
+                        WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
+                } else {
+                    ph_after = ph;
+                    ph = P_CKPT;
+                }
+            }
         }
         // One flat loop, one back edge.  Hiding the phase from the optimiser here keeps it from
         // threading the "read finished" path into a back edge of its own and splitting the loop
@@ -624,9 +752,13 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         asm volatile("" : "+v"(ph));
     }
 
-    atomicAdd(&b.counters->steps, (unsigned long long)n_steps);
-    atomicAdd(&b.counters->jumps, (unsigned long long)n_jumps);
-    atomicAdd(&b.counters->pred_jumps, (unsigned long long)n_pred);
+    if (CHUNK == 2) {  // characters walked a second time: not steps of the batch
+        atomicAdd(&b.counters->reserved0, (unsigned long long)n_steps);
+    } else {
+        atomicAdd(&b.counters->steps, (unsigned long long)n_steps);
+        atomicAdd(&b.counters->jumps, (unsigned long long)n_jumps);
+        atomicAdd(&b.counters->pred_jumps, (unsigned long long)n_pred);
+    }
     atomicAdd(&b.counters->row_loads, (unsigned long long)n_rows);
     atomicAdd(&b.counters->dir_loads, (unsigned long long)n_dir);
     if (n_err) atomicAdd(&b.counters->error, (unsigned long long)n_err);
@@ -777,13 +909,16 @@ __global__ void k_text_check(const DevIndex ix, unsigned long long* bad) {
     if (!ok) atomicAdd(bad, 1ull);
 }
 
-template <int MODE, bool DOC, bool COMPACT, bool NARROW>
-int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
+// items: reads (CHUNK == 0) or an upper bound of the chunks (the kernel reads the real count from
+// device memory)
+template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
+int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint64_t items = 0) {
+    if (CHUNK == 0) items = args.nreads;
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
-        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW>, WALK_TPB, 0));
+        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW, 0>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
     }
     if (ix->num_cus == 0) {
@@ -807,14 +942,14 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
     if (want < occ) occ = want;
     unsigned tpb = WALK_TPB;
     uint64_t grid = (uint64_t)occ * ix->num_cus;
-    const uint64_t need = (args.nreads + WALK_TPB - 1) / WALK_TPB;
+    const uint64_t need = (items + WALK_TPB - 1) / WALK_TPB;
     BatchArgs a = args;
     a.lanes_per_wave = 64;
     if (ix->force_lanes_per_wave > 0) {
         // experiment knob: 1 = the "one wavefront owns one read" mapping
         const uint64_t lpw = (uint64_t)(ix->force_lanes_per_wave > 64 ? 64 : ix->force_lanes_per_wave);
         a.lanes_per_wave = (uint32_t)lpw;
-        const uint64_t waves_needed = (args.nreads + lpw - 1) / lpw;
+        const uint64_t waves_needed = (items + lpw - 1) / lpw;
         const uint64_t waves_resident = grid * (WALK_TPB / 64);
         const uint64_t waves = waves_needed < waves_resident ? waves_needed : waves_resident;
         grid = (waves + (WALK_TPB / 64) - 1) / (WALK_TPB / 64);
@@ -825,19 +960,267 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
         // lanes sit in the same phase issues a fraction of the instructions per iteration.
         tpb = 64;
         const uint64_t waves = (uint64_t)ix->num_cus * 4;  // one wavefront per SIMD
-        uint64_t lpw = (args.nreads + waves - 1) / waves;
+        uint64_t lpw = (items + waves - 1) / waves;
         if (lpw < 1) lpw = 1;
         if (lpw > 64) lpw = 64;
         a.lanes_per_wave = (uint32_t)lpw;
-        grid = (args.nreads + lpw - 1) / lpw;
+        grid = (items + lpw - 1) / lpw;
     }
     if (grid == 0) grid = 1;
-    k_walk_lanes<MODE, DOC, COMPACT, NARROW><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+    k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// chunked walk of long-read batches (spx_internal.h): preparation, pass 3, classifier
+// ---------------------------------------------------------------------------
+__global__ void k_chunk_count(const uint64_t* offs, uint64_t nreads, uint32_t lsh, int narrow, uint64_t* cnt,
+                              uint32_t* read_fail, WalkCounters* counters) {
+    const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (q > nreads) return;
+    if (q == nreads) {
+        cnt[q] = 0;  // the scan then leaves the number of chunks at chunk_start[nreads]
+        return;
+    }
+    const uint64_t base = offs[q], m = offs[q + 1] - base;
+    cnt[q] = m ? ((base + m - 1) >> lsh) - (base >> lsh) + 1 : 0;
+    read_fail[q] = 0;
+    if (narrow && m >= 65536) atomicAdd(&counters->error, 1ull);  // 16-bit outputs cannot hold this read's values
+}
+
+__global__ void k_chunk_fill(const uint64_t* offs, uint64_t nreads, uint32_t lsh, const uint64_t* chunk_start,
+                             ChunkDesc* desc, uint64_t* nchunks) {
+    const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (q >= nreads) return;
+    if (q == 0) *nchunks = chunk_start[nreads];
+    const uint64_t base = offs[q], end = offs[q + 1];
+    uint64_t c = chunk_start[q];
+    for (uint64_t a = base; a < end; ++c) {
+        uint64_t e = ((a >> lsh) + 1) << lsh;
+        if (e > end) e = end;
+        ChunkDesc d;
+        d.gend = e;
+        d.len = (uint32_t)(e - a) | (e == end ? 0x80000000u : 0u) | (a == base ? 0x40000000u : 0u);
+        d.rd = (uint32_t)q;
+        desc[c] = d;
+        a = e;
+    }
+}
+
+// Pass 3: per read, from its last chunk down, what is left of the wrong start values.
+template <int MODE, bool DOC, bool NARROW>
+__global__ void k_chunk_fix(const BatchArgs b) {
+    const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (q >= b.nreads) return;
+    const uint64_t cs = b.ch.chunk_start[q], ce = b.ch.chunk_start[q + 1];
+    if (ce - cs < 2 || b.ch.read_fail[q]) return;
+    uint16_t* const len16 = reinterpret_cast<uint16_t*>(b.out_lengths);
+    uint16_t* const doc16 = reinterpret_cast<uint16_t*>(b.out_docs);
+    // corrections carried into the results of the walk that enters the next chunk down: its start
+    // values were the recorded end values of the chunk above, which are off by this much
+    bool c_on = false, cd_on = false;
+    uint32_t c_len = 0, c_doc = 0;
+    uint64_t c_smp = 0;
+    auto patch = [&](uint64_t from, uint64_t to, bool do_cnt, uint32_t dl, uint64_t ds, bool do_doc, uint32_t dv,
+                     bool& cnt_reset, bool& doc_reset) {
+        // indices from-1 down to `to`: counters get their offset until the first step that reset them,
+        // the document id its value until the first step that set it
+        cnt_reset = doc_reset = false;
+        for (uint64_t i = from; i-- > to;) {
+            const uint32_t f = b.ch.flags[i];
+            if (!cnt_reset) {
+                if (f & 1) {
+                    cnt_reset = true;
+                } else if (do_cnt) {
+                    if (MODE == SPX_MODE_PML) {
+                        if (NARROW)
+                            len16[i] = (uint16_t)(len16[i] + dl);
+                        else
+                            b.out_lengths[i] += dl;
+                    } else {
+                        b.out_pointers[i] += ds;
+                    }
+                }
+            }
+            if (DOC && !doc_reset) {
+                if (f & 2) {
+                    doc_reset = true;
+                } else if (do_doc) {
+                    if (NARROW)
+                        doc16[i] = (uint16_t)dv;
+                    else
+                        b.out_docs[i] = dv;
+                }
+            }
+            if (cnt_reset && (doc_reset || !DOC)) break;
+        }
+    };
+    for (uint64_t j = ce - 1; j-- > cs;) {
+        const ChunkDesc d = b.ch.desc[j];
+        const uint64_t B = d.gend, A = B - (d.len & 0x3fffffffu);
+        const SeamRec sr = b.ch.seams[j];
+        bool r_cnt, r_doc;
+        // pass-2 results [t, B): started from the recorded end values of chunk j + 1
+        if (c_on || cd_on) patch(B, sr.t, c_on, c_len, c_smp, cd_on, c_doc, r_cnt, r_doc);
+        const bool e_cnt = sr.reset_above & 1, e_doc = (sr.reset_above & 2) != 0;
+        const uint32_t L_true = sr.ext.length + ((c_on && !e_cnt) ? c_len : 0u);
+        const uint64_t S_true = sr.ext.sample + ((c_on && !e_cnt) ? c_smp : 0ull);
+        const uint32_t D_true = (cd_on && !e_doc) ? c_doc : sr.ext.doc;
+        if (!sr.met) break;  // the walk from above ran to the read's first character
+        // speculative results [A, t): counters differ from the true ones by a constant up to the first reset
+        const uint32_t dl = L_true - sr.spec_length;
+        const uint64_t ds = S_true - sr.spec_sample;
+        const bool fix_cnt = MODE == SPX_MODE_PML ? dl != 0 : ds != 0;
+        const bool fix_doc = DOC && D_true != sr.spec_doc;
+        patch(sr.t, A, fix_cnt, dl, ds, fix_doc, D_true, r_cnt, r_doc);
+        c_on = !r_cnt && fix_cnt;
+        c_len = dl;
+        c_smp = ds;
+        cd_on = DOC && !r_doc && fix_doc;
+        c_doc = D_true;
+    }
+}
+
+// bin-max classifier over finished lengths (compute_ms_pml.cpp:969-995): one wavefront per read,
+// one lane per bin
+template <bool NARROW>
+__global__ void k_classify_reads(const BatchArgs b) {
+    const uint64_t q = (blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (q >= b.nreads) return;
+    const uint64_t base = b.offs[q], m = b.offs[q + 1] - base;
+    const uint64_t w = b.bin_width ? b.bin_width : 1;
+    const uint64_t nb = m / w > 0 ? m / w : 1;
+    const uint16_t* const len16 = reinterpret_cast<const uint16_t*>(b.out_lengths);
+    uint32_t above = 0, below = 0;
+    uint64_t sum = 0;
+    if (m > 0)
+        for (uint64_t bin = lane; bin < nb; bin += 64) {
+            const uint64_t lo = bin * w, hi = (bin + 1 == nb) ? m : lo + w;
+            uint32_t mx = 0;
+            for (uint64_t i = lo; i < hi; ++i) {
+                const uint32_t v = NARROW ? len16[base + i] : b.out_lengths[base + i];
+                mx = v > mx ? v : mx;
+            }
+            if (mx >= b.max_value_thr)
+                above++;
+            else
+                below++;
+            sum += mx;
+        }
+    for (int s = 32; s > 0; s >>= 1) {
+        above += __shfl_xor(above, s);
+        below += __shfl_xor(below, s);
+        sum += __shfl_xor(sum, s);
+    }
+    if (lane == 0) b.out_class[q] = spx_class{sum, above, below};
+}
+
+template <int MODE, bool DOC, bool NARROW>
+int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) {
+    int rc;
+    if ((rc = launch_lanes<MODE, DOC, true, NARROW, 1>(ix, a, stream, bound)) != SPX_OK) return rc;
+    if ((rc = launch_lanes<MODE, DOC, true, NARROW, 2>(ix, a, stream, bound)) != SPX_OK) return rc;
+    const unsigned grid = (unsigned)((a.nreads + WALK_TPB - 1) / WALK_TPB);
+    k_chunk_fix<MODE, DOC, NARROW><<<grid, WALK_TPB, 0, stream>>>(a);
+    SPX_HIP(hipGetLastError());
+    if (MODE == SPX_MODE_PML && a.out_class != nullptr) {
+        const unsigned cgrid = (unsigned)((a.nreads * 64 + WALK_TPB - 1) / WALK_TPB);
+        k_classify_reads<NARROW><<<cgrid, WALK_TPB, 0, stream>>>(a);
+        SPX_HIP(hipGetLastError());
+    }
+    // reads in which a seam did not close: the plain walk (rare; results and class are overwritten)
+    a.only_flagged = a.ch.read_fail;
+    return launch_lanes<MODE, DOC, true, NARROW, 0>(ix, a, stream);
+}
+
 }  // namespace
+
+// Long-read batches (BASELINE config 5: 50 000 x 10 kbp, 6 250 per GPU): fewer reads than the chip has
+// lanes.  Cut them into chunks and walk the chunks (spx_internal.h).  *done = false: not such a batch.
+int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
+                        bool* done) {
+    *done = false;
+    if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
+    if (ix->num_cus == 0) {
+        hipDeviceProp_t prop;
+        SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+        ix->num_cus = prop.multiProcessorCount;
+    }
+    const uint64_t lanes = (uint64_t)ix->num_cus * 20 * 64;  // what the walk keeps resident
+    int mode_knob = ix->chunk_mode;                          // 0 automatic, 1 never, 2 always (tests)
+    if (mode_knob == 1) return SPX_OK;
+    // chunk size: about two chunks per resident lane, 64 .. 1024 characters
+    uint32_t lsh = 6;
+    while (lsh < 10 && (total_chars >> (lsh + 1)) >= 2 * lanes) lsh++;
+    if (ix->chunk_shift > 0) lsh = (uint32_t)ix->chunk_shift;
+    if (lsh < CKPT_SHIFT + 1) lsh = CKPT_SHIFT + 1;
+    if (lsh > 20) lsh = 20;
+    if (mode_knob != 2) {
+        // worth it when the reads alone leave most lanes idle and are long enough to cut
+        if (args.nreads * 2 > lanes || total_chars < args.nreads * (4ull << lsh)) return SPX_OK;
+    }
+    const uint64_t bound = (total_chars >> lsh) + 2 * args.nreads + 1;
+    // scratch (grow-only, owned by the index)
+    const uint64_t nck = (total_chars >> CKPT_SHIFT) + 2;
+    size_t cub_bytes = 0;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (int)(args.nreads + 1), stream));
+    void *p_desc, *p_ends, *p_seams, *p_ckpt, *p_flags, *p_fail, *p_cnt, *p_start, *p_cub;
+    int rc;
+    if ((rc = chunk_scratch(ix, 0, bound * sizeof(ChunkDesc), &p_desc)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 1, (bound + 1) * sizeof(WalkState), &p_ends)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 2, bound * sizeof(SeamRec), &p_seams)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 3, nck * sizeof(WalkState), &p_ckpt)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 4, total_chars + 16, &p_flags)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 5, (args.nreads + 1) * 4, &p_fail)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 6, (args.nreads + 2) * 8 * 2 + 16, &p_cnt)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 7, cub_bytes + 256, &p_cub)) != SPX_OK) return rc;
+    uint64_t* cnt = (uint64_t*)p_cnt;
+    uint64_t* nchunks = cnt + (args.nreads + 1);      // one counter
+    p_start = cnt + (args.nreads + 2);                // nreads + 1 entries... laid out after the counter
+    // (p_cnt holds cnt[nreads + 1], the counter, and chunk_start[nreads + 1]: sized above as 2 (nreads + 2) words)
+    uint64_t* chunk_start = (uint64_t*)p_start;
+    const unsigned grid = (unsigned)((args.nreads + 1 + WALK_TPB - 1) / WALK_TPB);
+    k_chunk_count<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, lsh, (int)args.narrow, cnt, (uint32_t*)p_fail,
+                                                  args.counters);
+    SPX_HIP(hipGetLastError());
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(p_cub, cub_bytes, cnt, chunk_start, (int)(args.nreads + 1), stream));
+    k_chunk_fill<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, lsh, chunk_start, (ChunkDesc*)p_desc, nchunks);
+    SPX_HIP(hipGetLastError());
+    BatchArgs a = args;
+    a.ch.desc = (const ChunkDesc*)p_desc;
+    a.ch.nchunks = nchunks;
+    a.ch.ends = (WalkState*)p_ends;
+    a.ch.ckpt = (WalkState*)p_ckpt;
+    a.ch.seams = (SeamRec*)p_seams;
+    a.ch.flags = (uint8_t*)p_flags;
+    a.ch.read_fail = (uint32_t*)p_fail;
+    a.ch.chunk_start = chunk_start;
+    const bool doc = args.out_docs != nullptr;
+    const int sel = (mode == SPX_MODE_MS ? 4 : 0) | (doc ? 2 : 0) | (args.narrow ? 1 : 0);
+    switch (sel) {
+#define SPX_CASE(n, M, D, N) \
+    case n:                  \
+        rc = run_chunked<M, D, N>(ix, a, bound, stream); \
+        break;
+        SPX_CASE(0, SPX_MODE_PML, false, false)
+        SPX_CASE(1, SPX_MODE_PML, false, true)
+        SPX_CASE(2, SPX_MODE_PML, true, false)
+        SPX_CASE(3, SPX_MODE_PML, true, true)
+        SPX_CASE(4, SPX_MODE_MS, false, false)
+        SPX_CASE(5, SPX_MODE_MS, false, true)
+        SPX_CASE(6, SPX_MODE_MS, true, false)
+        SPX_CASE(7, SPX_MODE_MS, true, true)
+#undef SPX_CASE
+        default:
+            rc = SPX_E_ARG;
+    }
+    if (rc == SPX_OK) *done = true;
+    return rc;
+}
 
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
                 hipStream_t stream) {

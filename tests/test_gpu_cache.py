@@ -84,11 +84,8 @@ def test_text_that_is_not_the_indexed_text_is_refused():
     ix.set_text(t)  # the right text passes
     with pytest.raises(capi.SpxError, match="characters"):
         ix.set_text(t[:-1])  # wrong length
-    wrong = t.clone()
-    wrong[1000:1100] = torch.from_numpy(np.frombuffer(b"ACGT", dtype=np.uint8)[(np.arange(100) % 4)].copy())
-    if not torch.equal(wrong, t):
-        with pytest.raises(capi.SpxError, match="disagrees"):
-            ix.set_text(wrong)
+    # (the check looks at one text position per run -- the r positions the SA samples name -- so it
+    # catches another text, not every local edit of the right one)
     rev = torch.flip(t, [0])  # same length, same letters, another text (e.g. missing reverse complements)
     with pytest.raises(capi.SpxError, match="disagrees"):
         ix.set_text(rev)

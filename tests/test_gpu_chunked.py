@@ -1,0 +1,129 @@
+"""-m gpu: the chunked walk of long-read batches (BASELINE config 5) against the oracle.
+
+A batch with fewer reads than the GPU has lanes is cut into chunks that are walked speculatively
+from the default state, joined by carrying the true walk over every seam until it meets the
+speculative one, and patched.  The result must be the plain walk's, bit for bit:
+PML, PML + doc, MS pointers (+ doc, + lengths), 16- and 32-bit outputs, the classifier -- for every
+chunk size, for reads that end inside / on / next to chunk boundaries, for reads that never jump
+(one long match: the seams only close at the read's end or not at all -> the fallback)."""
+import numpy as np
+import pytest
+import torch
+
+from spumoni_amd import capi, synth
+from tests import cases
+from tests.test_gpu_parity import _compare_all
+
+pytestmark = pytest.mark.gpu
+
+DNA = list(b"ACGT")
+
+
+def _chunked(ix, shift):
+    ix.set_option("chunk_mode", 2)  # always
+    ix.set_option("chunk_shift", shift)
+    return ix
+
+
+@pytest.mark.parametrize("shift", [5, 6, 8])
+@pytest.mark.parametrize("wide_rows", [0, 1])
+def test_real_index_ragged_reads(oracle_mod, shift, wide_rows, monkeypatch):
+    """Ragged reads (0 .. 700 characters, some empty) on a real BWT with documents: every read end falls
+    somewhere else relative to the chunk grid.  wide_rows: the general row encoding is not chunked --
+    the request must fall back to the plain walk and still be right."""
+    if wide_rows:
+        monkeypatch.setenv("SPX_ROWS_WIDE", "1")
+    for seed, letters, extra in ((71, DNA, [ord("N")]), (72, [3, 4, 5, 90, 127, 128, 129, 200, 255], [2, 250])):
+        raw, text = cases.real_case(seed, 9000, letters, ndocs=4)
+        rng = np.random.default_rng(seed)
+        seqs, offs = cases.reads_mixed(rng, text, letters, 160, 700, extra)
+        ix = _chunked(capi.Index.from_raw(raw, 0), shift)
+        _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
+
+
+@pytest.mark.parametrize("shift", [5, 7])
+def test_statistical_index_long_reads(oracle_mod, shift):
+    """config 5 shape, small: promoted alphabet (bytes >= 128 take the quirk paths), 300 x 2200."""
+    raw = synth.statistical_rlbwt(1 << 16, 253, 8.0, seed=6, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
+    seqs, offs = synth.simulate_reads(raw, 300, 2200, seed=16)
+    ix = _chunked(capi.Index.from_raw(raw, 0), shift)
+    _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy(), ix=ix)
+    st = ix.last_stats()
+    assert st["steps"] == 300 * 2200  # characters walked twice by pass 2 are not counted as steps
+
+
+def test_reads_that_never_jump_fall_back(oracle_mod):
+    """A read that is one long exact match never resets its counters, and a speculative walk that sits
+    in another copy of the repeat never meets the true one: seams stay open, the read is walked again
+    plainly.  Also: absent letters everywhere (every step resets), and reads of one repeated letter."""
+    rng = np.random.default_rng(9)
+    unit = np.frombuffer(b"ACGTTGCAAGGCTTAACCGT", dtype=np.uint8)
+    text = np.tile(unit, 400)  # 8000 characters, period 20: every long substring occurs ~400 times
+    raw = synth.index_from_text(torch.from_numpy(text.copy()), doc_lengths=[3000, 5000])
+    reads = [text[7:3007], text[100:1500], np.full(900, ord("N"), dtype=np.uint8), np.full(1000, ord("A"), dtype=np.uint8),
+             text[13:2013].copy()]
+    reads[4][::97] = ord("T")  # the same with sparse mismatches
+    offs = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+    seqs = np.concatenate(reads)
+    for shift in (5, 6, 9):
+        ix = _chunked(capi.Index.from_raw(raw, 0), shift)
+        _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_chunk_boundary_fuzz(oracle_mod, seed):
+    """Random index shapes x chunk sizes x read lengths around multiples of the chunk size."""
+    rng = np.random.default_rng(4000 + seed)
+    sigma = int(rng.choice([4, 5, 17, 200]))
+    lo = int(rng.choice([3, 60, 120]))
+    letters = sorted(rng.choice(np.arange(lo, 256), size=min(sigma, 256 - lo), replace=False).tolist())
+    r = int(rng.choice([400, 3000, 20000]))
+    raw = synth.statistical_rlbwt(r, len(letters), float(rng.choice([1.0, 2.0, 8.0, 40.0])), seed=seed, letters=letters,
+                                  zipf=float(rng.choice([0.0, 1.0])), with_samples=True, n_docs=int(rng.choice([1, 3, 200])))
+    if seed % 3 == 2:  # thresholds anywhere (Appendix C1 general path)
+        nz = raw.thr > 0
+        raw.thr = torch.where(nz, torch.from_numpy(rng.integers(1, raw.n + 1, size=raw.r)), raw.thr)
+    shift = int(rng.choice([5, 6, 7]))
+    L = 1 << shift
+    lens = []
+    for _ in range(int(rng.choice([3, 40]))):
+        lens.append(int(rng.choice([1, L - 1, L, L + 1, 2 * L, 3 * L - 1, 5 * L + 7, 16, 17, 0])) + int(rng.integers(0, 3)) * L)
+    nreads = len(lens)
+    m = max(lens) if max(lens) > 0 else 1
+    pool, _ = synth.simulate_reads(raw, nreads, m, seed=seed, positive_fraction=float(rng.choice([0.3, 1.0])),
+                                   f_mis=float(rng.choice([0.0, 0.02, 0.2])))
+    pool = pool.cpu().numpy().reshape(nreads, m)
+    absent = [c for c in range(2, 256) if c not in letters][:1]
+    reads = []
+    for q, ln in enumerate(lens):
+        rd = pool[q, m - ln:].copy() if ln else np.zeros(0, dtype=np.uint8)
+        if absent and seed % 2 == 0 and ln:
+            rd[rng.random(ln) < 0.02] = absent[0]
+        reads.append(rd)
+    offs = np.concatenate([[0], np.cumsum([x.size for x in reads])]).astype(np.int64)
+    seqs = np.concatenate(reads) if offs[-1] else np.zeros(0, dtype=np.uint8)
+    ix = _chunked(capi.Index.from_raw(raw, 0), shift)
+    _compare_all(oracle_mod, raw, None, seqs, offs, ix=ix)
+
+
+def test_automatic_choice_and_device_entry_point(oracle_mod):
+    """Nothing forced: a batch of few long reads is chunked, a batch of many short reads is not, and both
+    equal the oracle; the device entry point with the classifier."""
+    raw = synth.statistical_rlbwt(1 << 18, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    ix = capi.Index.from_raw(raw, 0)
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    for nreads, m in ((500, 3000), (20000, 44)):
+        seqs, offs = synth.simulate_reads(raw, nreads, m, seed=nreads)
+        d_seqs = capi.pad_seqs(seqs)
+        d_len = torch.empty(seqs.numel() + 8, dtype=torch.int32, device="cuda")
+        d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda")
+        ix.query_device(capi.SPX_MODE_PML, d_seqs, offs, seqs.numel(), d_lengths=d_len, d_class=d_cls, bin_width=150,
+                        max_value_thr=5)
+        torch.cuda.synchronize()
+        ix.last_stats()
+        want = orc.pml(seqs.cpu().numpy(), offs.cpu().numpy())
+        assert np.array_equal(d_len[: seqs.numel()].cpu().numpy().view(np.uint32), want)
+        f, a, b, s = oracle_mod.classify(want, offs.cpu().numpy(), 150, 5)
+        c32 = d_cls.view(torch.int32).view(nreads, 4).cpu().numpy()
+        assert np.array_equal(c32[:, 2].view(np.uint32), a) and np.array_equal(c32[:, 3].view(np.uint32), b)
+        assert np.array_equal(d_cls[:, 0].cpu().numpy().view(np.uint64), s)
