@@ -177,6 +177,15 @@ int spx_query_batch_device16(spx_index *ix, int mode, const uint8_t *d_seqs,
  * (synchronises with that query).                                            */
 int spx_last_walk_stats(spx_index *ix, spx_walk_stats *out);
 
+/* Long-read batches (fewer reads than the GPU has lanes) are cut into chunks that are walked
+ * concurrently and joined exactly; results are the plain walk's, bit for bit.
+ * out[0] = chunk size of the last query in characters (0: it ran the plain walk), out[1] = upper
+ * bound of its chunks, out[2] = characters walked a second time to join chunks, out[3] = reads
+ * whose chunks did not join and that were walked again the plain way.
+ * Knobs (spx_set_option): "chunk_mode" 0 automatic / 1 never / 2 always, "chunk_shift" log2 of the
+ * chunk size (0 automatic).                                                                      */
+int spx_last_chunk_stats(spx_index *ix, uint64_t out[4]);
+
 /* Page-locked host memory for spx_query_batch's buffers: with buffers from
  * spx_host_alloc the copies run at PCIe DMA speed instead of through a pageable
  * staging copy (any host memory is accepted; this is only faster).  NULL on failure. */

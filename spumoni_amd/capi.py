@@ -47,6 +47,7 @@ EXPORTS = [
     "spx_index_load_flat",
     "spx_index_clone",
     "spx_index_describe",
+    "spx_last_chunk_stats",
 ]
 SPX_TEXT_UNCHECKED = 2
 
@@ -129,6 +130,7 @@ def lib() -> C.CDLL:
         L.spx_index_clone.restype = vp
         L.spx_index_clone.argtypes = [vp, i32]
         L.spx_index_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.spx_last_chunk_stats.argtypes = [vp, C.POINTER(u64 * 4)]
         _LIB = L
     return _LIB
 
@@ -351,6 +353,13 @@ class Index:
         if cls_ is not None:
             out["class"] = cls_[:nreads]
         return out
+
+    def last_chunk_stats(self) -> dict:
+        """Chunked walk of the last query: chunk size (0 = it ran the plain walk), characters walked a second
+        time to join the chunks, reads that fell back to the plain walk."""
+        o = (C.c_uint64 * 4)()
+        _check(lib().spx_last_chunk_stats(self._h, C.byref(o)))
+        return {"chunk_len": o[0], "chunks_bound": o[1], "rewalked_chars": o[2], "fallback_reads": o[3]}
 
     def last_stats(self) -> dict:
         s = SpxWalkStats()

@@ -349,6 +349,10 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->chunk_mode = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "chunk_len")) {  // chunk size in characters (0 = automatic)
+        ix->chunk_len = (int)value;
+        return SPX_OK;
+    }
     if (!strcmp(key, "chunk_shift")) {  // log2 of the chunk size (0 = automatic)
         ix->chunk_shift = (int)value;
         return SPX_OK;
@@ -513,7 +517,7 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     // the previous one (queries on one index are serialised, as the header promises)
     if (ix->have_timing && ix->last_stream != st) SPX_HIP(hipStreamWaitEvent(st, ix->ev_done, 0));
     SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), st));
-    BatchArgs a;
+    BatchArgs a{};
     a.seqs = d_seqs;
     a.offs = d_offsets;
     a.nreads = nreads;
@@ -630,7 +634,7 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         SPX_HIP(hipMemcpyAsync(d_seq + a, seqs + a, b - a, hipMemcpyHostToDevice, s_in));
         SPX_HIP(hipEventRecord(ix->pipe_in[c], s_in));
         SPX_HIP(hipStreamWaitEvent(s_k, ix->pipe_in[c], 0));
-        BatchArgs args;
+        BatchArgs args{};
         args.seqs = d_seq;
         args.offs = d_off + q0;
         args.nreads = q1 - q0;
@@ -1043,6 +1047,27 @@ int spx_index_describe(const spx_index* ix, char* buf, size_t cap) {
              (unsigned long long)v.nfat, (double)v.nfat / (double)(ix->r ? ix->r : 1), v.fat_stride,
              (int)ix->has_samples, (int)ix->has_docs, (unsigned long long)ix->n_text,
              (unsigned long long)(ix->device_bytes + ix->n_text));
+    return SPX_OK;
+}
+
+int spx_last_chunk_stats(spx_index* ix, uint64_t out[4]) {
+    if (!ix || !out) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->have_timing) {
+        set_error("no query has run on this index yet");
+        return SPX_E_ARG;
+    }
+    SPX_HIP(hipSetDevice(ix->device));
+    SPX_HIP(hipStreamSynchronize(ix->last_stream));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    out[0] = ix->last_chunk_len;
+    out[1] = ix->last_chunk_bound;
+    out[2] = wc.reserved0;
+    out[3] = wc.pad_;
     return SPX_OK;
 }
 

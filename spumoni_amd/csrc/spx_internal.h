@@ -45,8 +45,15 @@ struct WalkCounters {
 //           the next jump resets them, so what is left of a wrong start value is a constant
 //           offset (a stale value, for the document id) up to the first reset below each seam:
 //           patched from the recorded values;
-//   then the bin classifier runs over the finished lengths, and a read in which some seam did
-//   not close inside its chunk is simply walked again the plain way.
+//   What pass 2 wrote is only the truth if the state it entered the chunk with was: true for the
+//   chunk below a read's last, and from there down as long as every seam closed (the recorded end
+//   state of a chunk whose seam closed IS the true walk's).  A seam left open -- pass 2 reached the
+//   chunk's first character still apart from the speculative walk -- breaks the chain: between
+//   rounds a scan per read (k_chunk_scan) follows the chain down to the first open seam and has the
+//   chunk below it entered again in the next round, now with the state the true walk ended in, down
+//   to at least where the earlier, unfounded walk had stopped writing.  After the last round a read
+//   whose chain is still broken is walked again the plain way.  Then the bin classifier runs over
+//   the finished lengths.
 struct ChunkDesc {     // 16 B
     uint64_t gend;     // index (in the concatenated input) one past the chunk's last character
     uint32_t len;      // characters
@@ -62,7 +69,7 @@ struct WalkState {     // 32 B: what a walk carries from one character to the ne
 };
 struct SeamRec {       // 64 B, one per chunk that is not its read's last: where and how pass 2 ended
     uint64_t t;        // pass 2 stopped with the results of [t, chunk end) written; t == chunk start: never met
-    uint32_t met;      // 1: positions met at t; 0: ran to the chunk's start
+    uint32_t met;      // bit 0: positions met at t (0: ran to the chunk's start); bits 8..: round of pass 2
     uint32_t reset_above;  // pass 2 saw a reset between the chunk's end and t
     WalkState ext;     // pass 2's counters at t
     uint32_t spec_length, spec_doc;
@@ -77,9 +84,17 @@ struct ChunkArgs {
     WalkState* ckpt;             // per 16 characters of the input: state before character 16 * i - 1
     SeamRec* seams;              // per chunk
     uint8_t* flags;              // per character: bit 0 length / sample were reset, bit 1 doc was set
-    uint32_t* read_fail;         // per read: a seam did not close
+    uint32_t* read_fail;         // per read: the chain of seams is still broken after the last round
     const uint64_t* chunk_start; // per read: first chunk
+    WalkState* reentry;          // per chunk: state to enter it with in a later round (flags: how far down to write)
+    uint64_t* vtop;              // per read: chunks from here up hold the truth
+    uint32_t* pending;           // per round of pass 2: chunks to enter (round 1: unused)
+    uint32_t round;              // pass 2: 1 = every chunk but a read's last, later = the chunks below open seams
+    uint32_t last_round;         // pass 2: an open seam now condemns the read to the plain walk
 };
+constexpr uint32_t CHUNK_TOP = 0x80000000u, CHUNK_BOTTOM = 0x40000000u, CHUNK_ACTIVE = 0x20000000u;  // in ChunkDesc::len
+constexpr uint32_t CHUNK_LEN_MASK = 0x1fffffffu;
+constexpr int CHUNK_EXTRA_ROUNDS = 3;
 
 struct BatchArgs {
     const uint8_t* seqs;   // readable for round_up(total_chars, 4) + 32 bytes
@@ -145,6 +160,8 @@ struct spx_index {
     } scratch[8], chunk_scr[8];  // host-buffer queries; chunked walks (under mu)
     int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
     int chunk_shift = 0;  // "chunk_shift" option: log2 of the chunk size (0 = automatic)
+    int chunk_len = 0;    // "chunk_len" option: chunk size in characters (rounded up to 16; 0 = automatic)
+    uint64_t last_chunk_len = 0, last_chunk_bound = 0;  // last query: chunk size (0 = plain walk), chunk bound
 };
 
 namespace spx {

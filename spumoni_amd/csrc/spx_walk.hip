@@ -164,6 +164,8 @@ template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
 __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, const BatchArgs b) {
     constexpr bool AUX = (MODE == SPX_MODE_MS) || DOC;  // per-jump side data (samples / doc ids)
     const uint64_t nitems = CHUNK ? *b.ch.nchunks : b.nreads;  // work items: reads, or chunks
+    if (CHUNK == 2 && b.ch.round > 1 && b.ch.pending[b.ch.round] == 0) return;  // no seam was left open
+    if (CHUNK == 0 && b.only_flagged != nullptr && b.counters->pad_ == 0) return;  // no read fell back
     __shared__ LetterInfo s_let[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) s_let[t] = ix.letters[t];
     __syncthreads();
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // chunked walks
     uint32_t rflag = 0;      // what the current step reset: bit 0 length / sample, bit 1 document id
     uint64_t fb = 0;         // pass 1: flags of the aligned group of 8 characters, a byte each
-    uint32_t item_rd = 0, item_flags = 0, seen = 0, ph_after = P_LAND;
+    uint32_t item_rd = 0, item_flags = 0, seen = 0, ph_after = P_LAND, tlimit = 0xffffffffu;
     if (rd >= nitems || (threadIdx.x & 63) >= lpw) ph = P_DONE;
 #define STAND_ON(row)                                \
     do {                                             \
@@ -239,6 +241,15 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             thr_ok_k = row_thr_ok(row);              \
             room_k = row_room(row);                  \
         }                                            \
+    } while (0)
+// next work item of this lane: static striding, no atomics.  (Chunks taken from a shared counter as
+// lanes become free were tried: equal chunks end together, and a few hundred thousand atomics on one
+// address at once cost more than the imbalance they remove -- pass 1 5.1 instead of 4.3 ms.  The chunk
+// size is chosen so that every lane gets a whole number of chunks instead.)
+#define NEXT_ITEM()                               \
+    do {                                          \
+        rd += nlanes;                             \
+        ph = rd < nitems ? P_READ : P_DONE;       \
     } while (0)
 #define LF_TARGET()                                                      \
     do {                                                                 \
@@ -269,7 +280,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else if (ph == P_READ) {
             p0 = CHUNK ? reinterpret_cast<const char*>(b.ch.desc + rd) : off_b + rd * 8;
         } else if (CHUNK == 2 && ph == P_START) {
-            p0 = reinterpret_cast<const char*>(b.ch.ends + rd + 1);  // the chunk above is the next one
+            // round 1: the recorded end state of the chunk above (the next one); later: what the scan left
+            p0 = reinterpret_cast<const char*>(b.ch.round > 1 ? b.ch.reentry + rd : b.ch.ends + rd + 1);
         } else if (CHUNK == 2 && ph == P_CKPT) {
             p0 = reinterpret_cast<const char*>(b.ch.ckpt + ((base + x) >> CKPT_SHIFT));
         } else if (MODE == SPX_MODE_MS && ph == P_SAMP) {
@@ -389,46 +401,46 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             offp = (g1 == OFF_END) ? OFF_LAST : (offs_t)g1;
             sample = g2;
             doc = (uint32_t)g3;
+            // entered again: an earlier, unfounded walk wrote down to here -- write at least as far
+            tlimit = b.ch.round > 1 ? (uint32_t)(g3 >> 32) : 0xffffffffu;
             seen = 0;
             wbase = ~0ull;  // no characters yet: the first step fetches its window
             ph = P_LAND;
         } else if (CHUNK == 2 && ph == P_CKPT) {
             n_dir++;
             const uint64_t my_off = (offp == OFF_LAST) ? OFF_END : (uint64_t)offp;
-            if ((uint32_t)g0 == k0 && g1 == my_off) {
+            if ((uint32_t)g0 == k0 && g1 == my_off && x <= tlimit) {
                 // same position before the same character: from here on the speculative walk IS this walk
                 SeamRec sr;
                 sr.t = base + x;
-                sr.met = 1;
+                sr.met = 1 | (b.ch.round << 8);
                 sr.reset_above = seen;
                 sr.ext = WalkState{k0, length, my_off, sample, doc, seen};
                 sr.spec_length = (uint32_t)(g0 >> 32);
                 sr.spec_doc = (uint32_t)g3;
                 sr.spec_sample = g2;
                 b.ch.seams[rd] = sr;
-                rd += nlanes;
-                ph = rd < nitems ? P_READ : P_DONE;
+                NEXT_ITEM();
             } else {
                 ph = ph_after;
             }
         } else if (ph == P_READ) {
             if (CHUNK) {  // ChunkDesc: gend, len | top << 31 | bottom << 30, read
-                item_flags = (uint32_t)g1 >> 30;
+                item_flags = (uint32_t)g1 >> 29;  // bit 2 last chunk of its read, bit 1 first, bit 0 to be entered
                 item_rd = (uint32_t)(g1 >> 32);
-                m = (uint32_t)g1 & 0x3fffffffu;
+                m = (uint32_t)g1 & CHUNK_LEN_MASK;
                 base = g0 - m;
             } else {
                 base = g0;
                 m = (uint32_t)(g1 - g0);
             }
             if (CHUNK == 0 && b.only_flagged != nullptr && b.only_flagged[rd] == 0) m = 0;  // not this pass's read
-            if (CHUNK == 2 && (item_flags & 2)) {  // a read's last chunk was right from the start
-                rd += nlanes;
-                if (rd >= nitems) ph = P_DONE;
+            if (CHUNK == 2 && ((item_flags & 4) || (b.ch.round > 1 && !(item_flags & 1)))) {
+                // a read's last chunk was right from the start; later rounds: only below open seams
+                NEXT_ITEM();
             } else if (m == 0) {
                 if (want_class && b.only_flagged == nullptr) b.out_class[rd] = spx_class{0, 0, 0};
-                rd += nlanes;
-                if (rd >= nitems) ph = P_DONE;
+                NEXT_ITEM();
             } else {
                 if (NARROW && m >= 65536) n_err++;  // 16-bit outputs cannot hold this read's values
                 x = m;
@@ -695,17 +707,17 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     // read's first chunk (the read is done), otherwise the read is walked again plainly
                     SeamRec sr;
                     sr.t = base;
-                    sr.met = 0;
+                    sr.met = b.ch.round << 8;
                     sr.reset_above = seen;
-                    sr.ext = WalkState{k0, length, 0, sample, doc, seen};
+                    sr.ext = WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                     sr.spec_length = 0;
                     sr.spec_doc = 0;
                     sr.spec_sample = 0;
                     b.ch.seams[rd] = sr;
-                    if (!(item_flags & 1)) b.ch.read_fail[item_rd] = 1;
+                    // (k_chunk_scan has the chunk below entered with this state in the next round)
+                    (void)item_rd;
                 }
-                rd += nlanes;
-                ph = rd < nitems ? P_READ : P_DONE;
+                NEXT_ITEM();
             } else {
                 ph = P_LAND;
                 if (peek) {
@@ -976,7 +988,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
 // ---------------------------------------------------------------------------
 // chunked walk of long-read batches (spx_internal.h): preparation, pass 3, classifier
 // ---------------------------------------------------------------------------
-__global__ void k_chunk_count(const uint64_t* offs, uint64_t nreads, uint32_t lsh, int narrow, uint64_t* cnt,
+__global__ void k_chunk_count(const uint64_t* offs, uint64_t nreads, uint32_t L, int narrow, uint64_t* cnt,
                               uint32_t* read_fail, WalkCounters* counters) {
     const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
     if (q > nreads) return;
@@ -985,12 +997,12 @@ __global__ void k_chunk_count(const uint64_t* offs, uint64_t nreads, uint32_t ls
         return;
     }
     const uint64_t base = offs[q], m = offs[q + 1] - base;
-    cnt[q] = m ? ((base + m - 1) >> lsh) - (base >> lsh) + 1 : 0;
+    cnt[q] = m ? (base + m - 1) / L - base / L + 1 : 0;
     read_fail[q] = 0;
     if (narrow && m >= 65536) atomicAdd(&counters->error, 1ull);  // 16-bit outputs cannot hold this read's values
 }
 
-__global__ void k_chunk_fill(const uint64_t* offs, uint64_t nreads, uint32_t lsh, const uint64_t* chunk_start,
+__global__ void k_chunk_fill(const uint64_t* offs, uint64_t nreads, uint32_t L, const uint64_t* chunk_start,
                              ChunkDesc* desc, uint64_t* nchunks) {
     const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
     if (q >= nreads) return;
@@ -998,14 +1010,52 @@ __global__ void k_chunk_fill(const uint64_t* offs, uint64_t nreads, uint32_t lsh
     const uint64_t base = offs[q], end = offs[q + 1];
     uint64_t c = chunk_start[q];
     for (uint64_t a = base; a < end; ++c) {
-        uint64_t e = ((a >> lsh) + 1) << lsh;
+        uint64_t e = (a / L + 1) * L;
         if (e > end) e = end;
         ChunkDesc d;
         d.gend = e;
-        d.len = (uint32_t)(e - a) | (e == end ? 0x80000000u : 0u) | (a == base ? 0x40000000u : 0u);
+        d.len = (uint32_t)(e - a) | (e == end ? CHUNK_TOP : 0u) | (a == base ? CHUNK_BOTTOM : 0u);
         d.rd = (uint32_t)q;
         desc[c] = d;
         a = e;
+    }
+}
+
+// Between rounds of pass 2, one lane per read: follow the chain of seams down from where the truth is
+// known to reach (vtop).  The walk that entered chunk j - 1 in its latest run started from the true end
+// state of chunk j (invariant), so chunk j - 1 holds the truth; if its seam closed, the recorded end
+// state of chunk j - 1 is the true one and the chain goes on with the round-1 walk of chunk j - 2; if
+// not, chunk j - 2 is entered again in the next round with the state the walk through chunk j - 1 ended
+// in.  After the last round a read whose chain has not reached its first chunk is marked for the plain walk.
+__global__ void k_chunk_scan(ChunkArgs ch, uint64_t nreads, uint32_t round, uint32_t last, WalkCounters* counters) {
+    const uint64_t q = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (q >= nreads) return;
+    const uint64_t cs = ch.chunk_start[q], ce = ch.chunk_start[q + 1];
+    if (ce - cs < 2) return;
+    ChunkDesc* desc = const_cast<ChunkDesc*>(ch.desc);
+    uint64_t j = round == 1 ? ce - 1 : ch.vtop[q];
+    if (j == cs) return;  // finished in an earlier round
+    if (round > 1) desc[j - 1].len &= ~CHUNK_ACTIVE;  // the chunk this round entered again
+    while (j > cs) {
+        const uint64_t nx = j - 1;
+        const SeamRec sr = ch.seams[nx];
+        j = nx;  // chunk nx holds the truth
+        if (nx == cs || (sr.met & 1)) continue;
+        if (!last) {  // open: the walk goes on into chunk nx - 1
+            WalkState st = sr.ext;
+            const ChunkDesc below = desc[nx - 1];
+            const SeamRec old = ch.seams[nx - 1];
+            st.flags = (uint32_t)(old.t - (below.gend - (below.len & CHUNK_LEN_MASK)));
+            ch.reentry[nx - 1] = st;
+            desc[nx - 1].len = below.len | CHUNK_ACTIVE;
+            atomicAdd(&ch.pending[round + 1], 1u);
+        }
+        break;
+    }
+    ch.vtop[q] = j;
+    if (last && j > cs) {
+        ch.read_fail[q] = 1;
+        atomicAdd(&counters->pad_, 1ull);  // reads walked again the plain way
     }
 }
 
@@ -1028,8 +1078,13 @@ __global__ void k_chunk_fix(const BatchArgs b) {
         // indices from-1 down to `to`: counters get their offset until the first step that reset them,
         // the document id its value until the first step that set it
         cnt_reset = doc_reset = false;
+        uint64_t w8 = 0, have = ~0ull;  // flags eight at a time: the aligned group that holds index i
         for (uint64_t i = from; i-- > to;) {
-            const uint32_t f = b.ch.flags[i];
+            if ((i & ~7ull) != have) {
+                have = i & ~7ull;
+                w8 = *reinterpret_cast<const uint64_t*>(b.ch.flags + have);
+            }
+            const uint32_t f = (uint32_t)(w8 >> ((i & 7) * 8)) & 0xffu;
             if (!cnt_reset) {
                 if (f & 1) {
                     cnt_reset = true;
@@ -1059,7 +1114,7 @@ __global__ void k_chunk_fix(const BatchArgs b) {
     };
     for (uint64_t j = ce - 1; j-- > cs;) {
         const ChunkDesc d = b.ch.desc[j];
-        const uint64_t B = d.gend, A = B - (d.len & 0x3fffffffu);
+        const uint64_t B = d.gend, A = B - (d.len & CHUNK_LEN_MASK);
         const SeamRec sr = b.ch.seams[j];
         bool r_cnt, r_doc;
         // pass-2 results [t, B): started from the recorded end values of chunk j + 1
@@ -1068,7 +1123,14 @@ __global__ void k_chunk_fix(const BatchArgs b) {
         const uint32_t L_true = sr.ext.length + ((c_on && !e_cnt) ? c_len : 0u);
         const uint64_t S_true = sr.ext.sample + ((c_on && !e_cnt) ? c_smp : 0ull);
         const uint32_t D_true = (cd_on && !e_doc) ? c_doc : sr.ext.doc;
-        if (!sr.met) break;  // the walk from above ran to the read's first character
+        if (!(sr.met & 1)) {
+            // the walk from above ran through the whole chunk: to the read's first character, or on into
+            // the chunk below (a later round of pass 2 entered it with this walk's state)
+            if (d.len & CHUNK_BOTTOM) break;
+            c_on = c_on && !e_cnt;
+            cd_on = cd_on && !e_doc;
+            continue;
+        }
         // speculative results [A, t): counters differ from the true ones by a constant up to the first reset
         const uint32_t dl = L_true - sr.spec_length;
         const uint64_t ds = S_true - sr.spec_sample;
@@ -1100,7 +1162,8 @@ __global__ void k_classify_reads(const BatchArgs b) {
         for (uint64_t bin = lane; bin < nb; bin += 64) {
             const uint64_t lo = bin * w, hi = (bin + 1 == nb) ? m : lo + w;
             uint32_t mx = 0;
-            for (uint64_t i = lo; i < hi; ++i) {
+#pragma unroll 8
+            for (uint64_t i = lo; i < hi; ++i) {  // independent loads: eight in flight
                 const uint32_t v = NARROW ? len16[base + i] : b.out_lengths[base + i];
                 mx = v > mx ? v : mx;
             }
@@ -1122,7 +1185,14 @@ template <int MODE, bool DOC, bool NARROW>
 int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) {
     int rc;
     if ((rc = launch_lanes<MODE, DOC, true, NARROW, 1>(ix, a, stream, bound)) != SPX_OK) return rc;
-    if ((rc = launch_lanes<MODE, DOC, true, NARROW, 2>(ix, a, stream, bound)) != SPX_OK) return rc;
+    for (int round = 1; round <= 1 + CHUNK_EXTRA_ROUNDS; ++round) {
+        a.ch.round = (uint32_t)round;
+        a.ch.last_round = round == 1 + CHUNK_EXTRA_ROUNDS;
+        if ((rc = launch_lanes<MODE, DOC, true, NARROW, 2>(ix, a, stream, bound)) != SPX_OK) return rc;
+        k_chunk_scan<<<(unsigned)((a.nreads + WALK_TPB - 1) / WALK_TPB), WALK_TPB, 0, stream>>>(
+            a.ch, a.nreads, (uint32_t)round, a.ch.last_round, a.counters);
+        SPX_HIP(hipGetLastError());
+    }
     const unsigned grid = (unsigned)((a.nreads + WALK_TPB - 1) / WALK_TPB);
     k_chunk_fix<MODE, DOC, NARROW><<<grid, WALK_TPB, 0, stream>>>(a);
     SPX_HIP(hipGetLastError());
@@ -1143,6 +1213,7 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
                         bool* done) {
     *done = false;
+    ix->last_chunk_len = ix->last_chunk_bound = 0;
     if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
     if (ix->num_cus == 0) {
         hipDeviceProp_t prop;
@@ -1152,31 +1223,45 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     const uint64_t lanes = (uint64_t)ix->num_cus * 20 * 64;  // what the walk keeps resident
     int mode_knob = ix->chunk_mode;                          // 0 automatic, 1 never, 2 always (tests)
     if (mode_knob == 1) return SPX_OK;
-    // chunk size: about two chunks per resident lane, 64 .. 1024 characters
-    uint32_t lsh = 6;
-    while (lsh < 10 && (total_chars >> (lsh + 1)) >= 2 * lanes) lsh++;
-    if (ix->chunk_shift > 0) lsh = (uint32_t)ix->chunk_shift;
-    if (lsh < CKPT_SHIFT + 1) lsh = CKPT_SHIFT + 1;
-    if (lsh > 20) lsh = 20;
+    // Chunk size (a multiple of the checkpoint spacing).  A seam closes within a few dozen characters
+    // (more for small alphabets: two walks approach each other by a factor of the alphabet per
+    // character), and every chunk costs that much again in pass 2, so chunks should not be short; but
+    // each lane should get a whole number of them: with k chunks per lane the chunk is
+    // total / (k * lanes) characters, k chosen for a chunk near the preferred size.
+    const uint32_t CK = 1u << CKPT_SHIFT;
+    // Every read end cuts one more chunk, so k chunks per lane means total / L + nreads <= k * lanes.
+    const uint32_t pref = ix->view.nletters > 16 ? 176 : 640, lo = ix->view.nletters > 16 ? 128 : 512;
+    uint64_t k = (total_chars / lanes + pref / 2) / pref;
+    if (k < 1) k = 1;
+    while (k * lanes <= args.nreads + args.nreads / 8) k++;
+    const uint64_t slots = k * lanes - args.nreads - args.nreads / 16;  // full chunks that fit
+    uint64_t L64 = ((total_chars + slots - 1) / slots + CK - 1) / CK * CK;
+    if (L64 < lo) L64 = lo;
+    if (L64 > 1024) L64 = 1024;
+    if (ix->chunk_shift > 0) L64 = 1ull << (ix->chunk_shift > 20 ? 20 : ix->chunk_shift);
+    if (ix->chunk_len > 0) L64 = ((uint64_t)ix->chunk_len + CK - 1) / CK * CK;
+    if (L64 < 2 * CK) L64 = 2 * CK;
+    const uint32_t L = (uint32_t)L64;
     if (mode_knob != 2) {
         // worth it when the reads alone leave most lanes idle and are long enough to cut
-        if (args.nreads * 2 > lanes || total_chars < args.nreads * (4ull << lsh)) return SPX_OK;
+        if (args.nreads * 2 > lanes || total_chars < args.nreads * (4ull * L)) return SPX_OK;
     }
-    const uint64_t bound = (total_chars >> lsh) + 2 * args.nreads + 1;
+    const uint64_t bound = total_chars / L + 2 * args.nreads + 1;
     // scratch (grow-only, owned by the index)
     const uint64_t nck = (total_chars >> CKPT_SHIFT) + 2;
     size_t cub_bytes = 0;
     SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
                                              (int)(args.nreads + 1), stream));
     void *p_desc, *p_ends, *p_seams, *p_ckpt, *p_flags, *p_fail, *p_cnt, *p_start, *p_cub;
+    const size_t fail_words = args.nreads + 1 + 16;  // per read, then the per-round counters
     int rc;
     if ((rc = chunk_scratch(ix, 0, bound * sizeof(ChunkDesc), &p_desc)) != SPX_OK) return rc;
-    if ((rc = chunk_scratch(ix, 1, (bound + 1) * sizeof(WalkState), &p_ends)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 1, 2 * (bound + 1) * sizeof(WalkState), &p_ends)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 2, bound * sizeof(SeamRec), &p_seams)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 3, nck * sizeof(WalkState), &p_ckpt)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 4, total_chars + 16, &p_flags)) != SPX_OK) return rc;
-    if ((rc = chunk_scratch(ix, 5, (args.nreads + 1) * 4, &p_fail)) != SPX_OK) return rc;
-    if ((rc = chunk_scratch(ix, 6, (args.nreads + 2) * 8 * 2 + 16, &p_cnt)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 5, fail_words * 4, &p_fail)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 6, (args.nreads + 2) * 8 * 3 + 16, &p_cnt)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 7, cub_bytes + 256, &p_cub)) != SPX_OK) return rc;
     uint64_t* cnt = (uint64_t*)p_cnt;
     uint64_t* nchunks = cnt + (args.nreads + 1);      // one counter
@@ -1184,11 +1269,11 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     // (p_cnt holds cnt[nreads + 1], the counter, and chunk_start[nreads + 1]: sized above as 2 (nreads + 2) words)
     uint64_t* chunk_start = (uint64_t*)p_start;
     const unsigned grid = (unsigned)((args.nreads + 1 + WALK_TPB - 1) / WALK_TPB);
-    k_chunk_count<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, lsh, (int)args.narrow, cnt, (uint32_t*)p_fail,
+    k_chunk_count<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, L, (int)args.narrow, cnt, (uint32_t*)p_fail,
                                                   args.counters);
     SPX_HIP(hipGetLastError());
     SPX_HIP(hipcub::DeviceScan::ExclusiveSum(p_cub, cub_bytes, cnt, chunk_start, (int)(args.nreads + 1), stream));
-    k_chunk_fill<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, lsh, chunk_start, (ChunkDesc*)p_desc, nchunks);
+    k_chunk_fill<<<grid, WALK_TPB, 0, stream>>>(args.offs, args.nreads, L, chunk_start, (ChunkDesc*)p_desc, nchunks);
     SPX_HIP(hipGetLastError());
     BatchArgs a = args;
     a.ch.desc = (const ChunkDesc*)p_desc;
@@ -1199,6 +1284,10 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     a.ch.flags = (uint8_t*)p_flags;
     a.ch.read_fail = (uint32_t*)p_fail;
     a.ch.chunk_start = chunk_start;
+    a.ch.reentry = (WalkState*)p_ends + (bound + 1);
+    a.ch.vtop = chunk_start + (args.nreads + 2);
+    a.ch.pending = (uint32_t*)p_fail + (args.nreads + 1);
+    SPX_HIP(hipMemsetAsync(a.ch.pending, 0, 16 * 4, stream));  // [0, 8) rounds, [8, 16) the passes' chunk counters
     const bool doc = args.out_docs != nullptr;
     const int sel = (mode == SPX_MODE_MS ? 4 : 0) | (doc ? 2 : 0) | (args.narrow ? 1 : 0);
     switch (sel) {
@@ -1218,7 +1307,11 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
         default:
             rc = SPX_E_ARG;
     }
-    if (rc == SPX_OK) *done = true;
+    if (rc == SPX_OK) {
+        *done = true;
+        ix->last_chunk_len = L;
+        ix->last_chunk_bound = bound;
+    }
     return rc;
 }
 

@@ -20,12 +20,16 @@ DNA = list(b"ACGT")
 
 
 def _chunked(ix, shift):
+    """shift < 20: chunks of 2^shift characters; otherwise the chunk size itself (any multiple of 16)."""
     ix.set_option("chunk_mode", 2)  # always
-    ix.set_option("chunk_shift", shift)
+    if shift < 20:
+        ix.set_option("chunk_shift", shift)
+    else:
+        ix.set_option("chunk_len", shift)
     return ix
 
 
-@pytest.mark.parametrize("shift", [5, 6, 8])
+@pytest.mark.parametrize("shift", [5, 6, 8, 48, 112])
 @pytest.mark.parametrize("wide_rows", [0, 1])
 def test_real_index_ragged_reads(oracle_mod, shift, wide_rows, monkeypatch):
     """Ragged reads (0 .. 700 characters, some empty) on a real BWT with documents: every read end falls
@@ -41,15 +45,19 @@ def test_real_index_ragged_reads(oracle_mod, shift, wide_rows, monkeypatch):
         _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
 
 
-@pytest.mark.parametrize("shift", [5, 7])
+@pytest.mark.parametrize("shift", [5, 7, 176])
 def test_statistical_index_long_reads(oracle_mod, shift):
     """config 5 shape, small: promoted alphabet (bytes >= 128 take the quirk paths), 300 x 2200."""
     raw = synth.statistical_rlbwt(1 << 16, 253, 8.0, seed=6, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
     seqs, offs = synth.simulate_reads(raw, 300, 2200, seed=16)
     ix = _chunked(capi.Index.from_raw(raw, 0), shift)
     _compare_all(oracle_mod, raw, None, seqs.cpu().numpy(), offs.cpu().numpy(), ix=ix)
-    st = ix.last_stats()
-    assert st["steps"] == 300 * 2200  # characters walked twice by pass 2 are not counted as steps
+    st, cs = ix.last_stats(), ix.last_chunk_stats()
+    assert cs["chunk_len"] == (1 << shift if shift < 20 else shift) and cs["rewalked_chars"] > 0
+    # characters walked a second time to join chunks are not steps; reads that fell back are walked again in full
+    assert 300 * 2200 <= st["steps"] <= 300 * 2200 + cs["fallback_reads"] * 2200
+    if shift >= 7:
+        assert cs["fallback_reads"] == 0  # chunks of 128 and more: a seam left open closes in the next round
 
 
 def test_reads_that_never_jump_fall_back(oracle_mod):
@@ -65,7 +73,7 @@ def test_reads_that_never_jump_fall_back(oracle_mod):
     reads[4][::97] = ord("T")  # the same with sparse mismatches
     offs = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
     seqs = np.concatenate(reads)
-    for shift in (5, 6, 9):
+    for shift in (5, 6, 9, 96):
         ix = _chunked(capi.Index.from_raw(raw, 0), shift)
         _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
 
@@ -83,8 +91,8 @@ def test_chunk_boundary_fuzz(oracle_mod, seed):
     if seed % 3 == 2:  # thresholds anywhere (Appendix C1 general path)
         nz = raw.thr > 0
         raw.thr = torch.where(nz, torch.from_numpy(rng.integers(1, raw.n + 1, size=raw.r)), raw.thr)
-    shift = int(rng.choice([5, 6, 7]))
-    L = 1 << shift
+    shift = int(rng.choice([5, 6, 7, 48, 80]))
+    L = 1 << shift if shift < 20 else shift
     lens = []
     for _ in range(int(rng.choice([3, 40]))):
         lens.append(int(rng.choice([1, L - 1, L, L + 1, 2 * L, 3 * L - 1, 5 * L + 7, 16, 17, 0])) + int(rng.integers(0, 3)) * L)

@@ -1,4 +1,12 @@
-"""End-to-end `spumoni run` (files in -> files out) on the 5-strain E. coli shape (run on the GPU box)."""
+"""End-to-end `spumoni run` (files in -> files out, on tmpfs) on the 5-strain E. coli shape.
+
+Run on the GPU box (gpurun).  Prints, for E2E_READS reads of 200 bp:
+  * our CLI: first run (raw index files -> flatten, SPUMONI_CACHE=write), second run (flat-layout
+    cache), SPUMONI_GPUS=0,0 (two workers, one queue), SPUMONI_REPORT_ONLY=1;
+  * the CPU oracle harness (oracle/orc_run, single thread, the reference's loop shape) on the first
+    E2E_CPU_READS reads: the file-emission-inclusive CPU baseline SURVEY 8(d) asks for;
+  * cmp of every output file of the two on that sample.
+"""
 import os, subprocess, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,7 +14,7 @@ sys.path.insert(0, ROOT)
 from spumoni_amd import synth
 from tests.sdsl_files import write_null_db
 
-d = "/tmp/e2e"; os.makedirs(d, exist_ok=True)
+d = os.environ.get("E2E_DIR", "/dev/shm/e2e"); os.makedirs(d, exist_ok=True)
 base = synth.random_genome(4_641_652, seed=1)
 genomes = [base] + [synth.mutate(base, seed=s) for s in (2, 3, 4, 5)]
 text, doc_lengths = synth.pangenome_text(genomes)
@@ -14,22 +22,65 @@ raw = synth.index_from_text(torch.from_numpy(text).cuda(), with_samples=False).c
 open(f"{d}/ref.fa", "w").write(">x\n")
 raw.write_raw_files(f"{d}/ref.fa")
 write_null_db(f"{d}/ref.fa.pmlnulldb", 3.0, [1, 2, 3, 3, 3, 3, 3])
-nreads, m = int(os.environ.get("E2E_READS", "1000000")), 200
+nreads, m = int(os.environ.get("E2E_READS", "4000000")), 200
+ncpu = int(os.environ.get("E2E_CPU_READS", "50000"))
 seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
-t0 = time.time()
-with open(f"{d}/reads.fa", "wb") as f:
+
+
+def write_fasta(path, lo, hi):
     rows = seqs.reshape(nreads, m)
-    hdr = np.array([f">read_{i}\n".encode().ljust(16, b" ") for i in range(nreads)])  # fixed-width ids
-    for i in range(0, nreads, 100000):
-        blk = b"".join(b">read_%d\n" % j + rows[j].tobytes() + b"\n" for j in range(i, min(nreads, i + 100000)))
-        f.write(blk)
-print(f"wrote reads.fa ({os.path.getsize(d + '/reads.fa')/1e6:.0f} MB) in {time.time()-t0:.1f}s")
-for rep in range(2):
+    with open(path, "wb") as f:
+        for i in range(lo, hi, 100000):
+            f.write(b"".join(b">read_%d\n" % j + rows[j].tobytes() + b"\n" for j in range(i, min(hi, i + 100000))))
+
+
+t0 = time.time()
+write_fasta(f"{d}/reads.fa", 0, nreads)
+write_fasta(f"{d}/sample.fa", 0, ncpu)
+print(f"wrote reads.fa ({os.path.getsize(d + '/reads.fa')/1e6:.0f} MB) in {time.time()-t0:.1f}s", flush=True)
+for f in os.listdir(d):
+    if f.endswith(".spx"):
+        os.remove(os.path.join(d, f))
+
+
+def run(tag, reads, extra_env):
+    env = dict(os.environ, **extra_env)
     t0 = time.time()
-    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", f"{d}/reads.fa", "-P", "-c", "-n"],
-                       capture_output=True, env=dict(os.environ, SPUMONI_TIMING="1"))
+    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", reads, "-P", "-c", "-n"],
+                       capture_output=True, env=env)
     dt = time.time() - t0
-    print([l for l in r.stderr.decode().splitlines() if "[timing]" in l])
-    print(r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "").strip().splitlines()[-4:])
-    print(f"spumoni run -P -c -n: {dt:.2f}s wall for {nreads} reads = {nreads/dt/1e6:.2f} M reads/s; "
-          f"pseudo_lengths {os.path.getsize(d + '/reads.fa.pseudo_lengths')/1e6:.0f} MB")
+    err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
+    assert r.returncode == 0, err
+    n = nreads if reads.endswith("reads.fa") else ncpu
+    load = [l for l in err.splitlines() if "loading the PML index" in l]
+    proc = [l for l in err.splitlines() if "processing the patterns" in l]
+    print(f"== {tag}: {dt:.2f}s wall, {n/dt/1e6:.2f} M reads/s end to end "
+          f"(pseudo_lengths {os.path.getsize(reads + '.pseudo_lengths')/1e6:.0f} MB)")
+    print("   ", (load + [""])[0].strip(), "|", (proc + [""])[0].strip())
+    for l in err.splitlines():
+        if "[timing]" in l:
+            print("   ", l.strip())
+    sys.stdout.flush()
+    return dt
+
+
+run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
+run("flat-layout cache", f"{d}/reads.fa", {})
+run("flat-layout cache, again", f"{d}/reads.fa", {})
+run("SPUMONI_GPUS=0,0 (two workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0"})
+run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
+# ---- CPU: the oracle harness, file to file, one thread (the reference's -t 1 shape) ----
+run("GPU CLI on the CPU sample", f"{d}/sample.fa", {})
+for ext in (".pseudo_lengths", ".report"):
+    os.replace(f"{d}/sample.fa{ext}", f"{d}/gpu_sample{ext}")
+orc = os.path.join(ROOT, "oracle", "orc_run")
+if os.path.exists(orc):
+    t0 = time.time()
+    r = subprocess.run([orc, f"{d}/ref.fa", f"{d}/sample.fa", "P", "0", "1", "150", "n"], capture_output=True)
+    dt = time.time() - t0
+    assert r.returncode == 0, r.stderr.decode()
+    print(f"== CPU oracle harness (1 thread, index load included): {dt:.2f}s wall for {ncpu} reads = {ncpu/dt/1e3:.1f} k reads/s, "
+          f"files written")
+    for ext in (".pseudo_lengths", ".report"):
+        same = subprocess.run(["cmp", f"{d}/sample.fa{ext}", f"{d}/gpu_sample{ext}"]).returncode == 0
+        print(f"   cmp {ext}: {'identical' if same else 'DIFFERENT'}")

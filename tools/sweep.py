@@ -9,6 +9,8 @@ def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=
     ix = capi.Index.from_raw(raw, 0)
     if waves: ix.set_option("waves_per_cu", waves)
     if lpw: ix.set_option("lanes_per_wave", lpw); tag = f"{tag} lanes/wave={lpw}"
+    if os.environ.get("SWEEP_CHUNK_MODE"): ix.set_option("chunk_mode", int(os.environ["SWEEP_CHUNK_MODE"]))
+    if os.environ.get("SWEEP_CHUNK_SHIFT"): ix.set_option("chunk_shift", int(os.environ["SWEEP_CHUNK_SHIFT"]))
     total = int(seqs.numel()); nreads = offs.numel() - 1
     d_seqs = capi.pad_seqs(seqs)
     d_len = torch.empty(total, dtype=torch.int32, device="cuda") if mode == capi.SPX_MODE_PML else None
@@ -26,7 +28,8 @@ def run(tag, raw, seqs, offs, mode=capi.SPX_MODE_PML, docs=False, waves=0, reps=
     bstep = 64 * (1 + 2 * f_mis + f_pred) + 1 + out_b + (4 if docs else 0)
     print(f"{tag:42s} r={raw.r:>11d} n/r={raw.n/raw.r:6.1f} waves={waves or 'max':>3} kernel {k:8.2f} ms  "
           f"{st['steps']/k/1e6:7.2f} Gsteps/s  {nreads/k/1e3:8.1f} Mreads/s  f_mis {f_mis:.3f} rows/step {st['row_loads']/st['steps']:.2f} "
-          f"dir/step {st['dir_loads']/st['steps']:.2f}  roofline {bstep*st['steps']/k/1e6/8000:.3f}  idx {ix.device_bytes/2**30:.1f} GiB", flush=True)
+          f"dir/step {st['dir_loads']/st['steps']:.2f}  roofline {bstep*st['steps']/k/1e6/8000:.3f}  idx {ix.device_bytes/2**30:.1f} GiB "
+          f"chunk {ix.last_chunk_stats()}", flush=True)
     ix.close()
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -49,11 +52,42 @@ if which in ("all", "ms"):
     del raw, seqs, offs
 if which in ("all", "long"):
     raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
-    seqs, offs = synth.simulate_reads(raw, 50_000, 2200, seed=16)
-    run("C5 long reads 50k x 2200", raw, seqs, offs)
-    seqs, offs = synth.simulate_reads(raw, 6_250, 2200, seed=17)
-    run("C5 per-GPU share 6250 x 2200", raw, seqs, offs)
-    del raw, seqs, offs
+    s50, o50 = synth.simulate_reads(raw, 50_000, 2200, seed=16)
+    s6, o6 = synth.simulate_reads(raw, 6_250, 2200, seed=17)
+    for cm, sh in (("1", ""), ("0", ""), ("2", "6"), ("2", "7"), ("2", "8")):
+        os.environ["SWEEP_CHUNK_MODE"] = cm
+        os.environ["SWEEP_CHUNK_SHIFT"] = sh or "0"
+        tag = {"1": "plain", "0": "auto"}.get(cm, f"chunk 2^{sh}")
+        run(f"C5 50k x 2200 [{tag}]", raw, s50, o50)
+        run(f"C5 share 6250 x 2200 [{tag}]", raw, s6, o6)
+    os.environ.pop("SWEEP_CHUNK_MODE"); os.environ.pop("SWEEP_CHUNK_SHIFT")
+    del raw, s50, o50, s6, o6
+if which in ("long1",):  # one configuration, for rocprofv3 --kernel-trace --stats
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    n1 = int(os.environ.get("LONG1_READS", "50000"))
+    s50, o50 = synth.simulate_reads(raw, n1, 2200, seed=16)
+    run(f"C5 {n1} x 2200 [auto]", raw, s50, o50, reps=5)
+if which in ("long2",):  # is pass 1 slower per step than the plain walk of as many short reads?
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    s1, o1 = synth.simulate_reads(raw, 860_000, 128, seed=16)
+    os.environ["SWEEP_CHUNK_MODE"] = "1"
+    run("plain 860k x 128", raw, s1, o1)
+    s2, o2 = synth.simulate_reads(raw, 2_500_000, 44, seed=16)
+    run("plain 2.5M x 44", raw, s2, o2)
+    s50, o50 = synth.simulate_reads(raw, 50_000, 2200, seed=16)
+    for w in (12, 16, 20, 24):
+        os.environ["SWEEP_CHUNK_MODE"] = "0"
+        run(f"chunked 50k x 2200 waves={w}", raw, s50, o50, waves=w)
+    os.environ.pop("SWEEP_CHUNK_MODE")
+if which in ("longdna",):
+    # un-digested long reads: DNA alphabet, 10 kbp
+    raw = synth.statistical_rlbwt(1 << 27, 4, 60.0, seed=4, device="cuda", letters=b"ACGT")
+    s6, o6 = synth.simulate_reads(raw, 6_250, 10_000, seed=17, f_mis=0.08)
+    for cm, sh in (("1", ""), ("0", ""), ("2", "7"), ("2", "8"), ("2", "9")):
+        os.environ["SWEEP_CHUNK_MODE"] = cm
+        os.environ["SWEEP_CHUNK_SHIFT"] = sh or "0"
+        run(f"C5 DNA 6250 x 10000 [{cm}/{sh}]", raw, s6, o6)
+    os.environ.pop("SWEEP_CHUNK_MODE"); os.environ.pop("SWEEP_CHUNK_SHIFT")
 if which in ("big",):
     t0 = time.time()
     raw = synth.statistical_rlbwt(1_000_000_000, 253, 8.0, seed=3, device="cuda", zipf=1.0)
