@@ -613,7 +613,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     fb |= (uint64_t)rflag << (slot * 8);
                     if (slot == 0 || xi == 0) {
                         const uint64_t g8 = gi & ~7ull;
+#ifdef SPX_EXP_NOFLAGS
+                        if (false) {
+#else
                         if (g8 >= base && g8 + 7 < base + m) {
+#endif
                             *reinterpret_cast<uint64_t*>(b.ch.flags + g8) = fb;
                         } else {
 #pragma unroll
@@ -748,7 +752,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             peek = false;
             if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
                 // checkpoint: the state before character base + x - 1
+#ifdef SPX_EXP_NOCKPT
+                if (false) {
+#else
                 if (CHUNK == 1) {
+#endif
                     b.ch.ckpt[(base + x) >> CKPT_SHIFT] =
                         WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                 } else {

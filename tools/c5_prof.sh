@@ -4,7 +4,7 @@ tag=${1:-c5}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for n in 50000 6250; do
+for n in ${C5_READS:-50000 6250}; do
   rm -rf /tmp/c5p
   LONG1_READS=$n rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5p -- python tools/sweep.py long1 > $out/run_$n.txt 2>/dev/null
   f=$(find /tmp/c5p -name "*kernel_stats.csv" | head -1)
