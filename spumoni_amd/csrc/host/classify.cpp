@@ -9,9 +9,11 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 
@@ -117,7 +119,7 @@ struct TextBuf {
         if (len + more > buf.size()) buf.resize(std::max(buf.size() * 2, len + more + (1u << 20)));
         return buf.data() + len;
     }
-    void header(const std::string& id) {
+    void header(std::string_view id) {
         char* p = reserve(id.size() + 2);
         *p++ = '>';
         std::memcpy(p, id.data(), id.size());
@@ -219,11 +221,13 @@ struct PinnedBuf {
 };
 
 struct SuperBatch {
-    std::vector<std::string> ids;
+    std::vector<std::string_view> ids;  // views into the mapped reads file (or into own_ids)
+    std::deque<std::string> own_ids;    // general-text reads are named here (a deque: addresses stay put)
     PinnedBuf<uint8_t> seqs;
     std::vector<uint64_t> offs{0};
     void clear() {
         ids.clear();
+        own_ids.clear();
         seqs.n = 0;
         offs.assign(1, 0);
     }
@@ -503,13 +507,13 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
     std::vector<size_t> take(nt, 0), chars(nt, 0);
     for (size_t t = 0; t < nt && !slot.deferred; ++t) {
         for (const ParsedRead& rd : parsed[t]) {
-            if (rd.seq.empty()) {  // :926-931
+            if (rd.seq().empty()) {  // :926-931
                 slot.deferred = 2;
-                slot.deferred_msg = rd.id;
+                slot.deferred_msg = std::string(rd.id);
                 break;
             }
             take[t]++;
-            chars[t] += rd.seq.size();
+            chars[t] += rd.seq().size();
         }
         if (!slot.deferred && errs[t].fatal) {
             slot.deferred = 1;
@@ -532,8 +536,8 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
         for (size_t q = 0; q < take[t]; ++q) {
             ParsedRead& rd = parsed[t][q];
             uint8_t* dst = slot.sb.seqs.data() + cpos;
-            const char* src = rd.seq.data();
-            const size_t len = rd.seq.size();
+            const char* src = rd.seq().data();
+            const size_t len = rd.seq().size();
             // make sure all characters are upper-case (:916-917; ::toupper in the "C" locale)
             for (size_t i = 0; i < len; ++i) {
                 const unsigned char ch = (unsigned char)src[i];
@@ -541,7 +545,7 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
             }
             cpos += len;
             slot.sb.offs[rdx + 1] = cpos;
-            slot.sb.ids[rdx] = std::move(rd.id);
+            slot.sb.ids[rdx] = rd.id;
             rdx++;
         }
     };
@@ -590,12 +594,18 @@ private:
     std::vector<std::pair<uint64_t, int>> done_;
 };
 
-size_t classify_reads(IndexSet& set, const RunOptions& o) {
+size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     Outputs out;
     const size_t max_value_thr = open_outputs_and_threshold(out, o);
     StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_write{"format+write", 0, {}};
     t_load.start();
-    ReadFile input(o.pattern_file);
+    // the reads file is mapped and its lines are found while the index loads (spumoni_main.cpp)
+    std::unique_ptr<ReadFile> own_input;
+    if (!preloaded) {
+        own_input.reset(new ReadFile(o.pattern_file, (unsigned)o.format_threads));
+        preloaded = own_input.get();
+    }
+    ReadFile& input = *preloaded;
     t_load.stop();
     // Parser -> ONE queue of parsed super-batches -> one worker thread per device -> ordered writer.
     // Every device pulls its next super-batch when it is free (reads are independent,
@@ -625,7 +635,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o) {
                 for (size_t q = 0; q < s.sb.nreads(); ++q)
                     if (s.res.beg[q] == s.res.end[q]) {
                         s.deferred = 2;
-                        s.deferred_msg = s.sb.ids[q];
+                        s.deferred_msg = std::string(s.sb.ids[q]);
                         s.sb.ids.resize(q);
                         s.sb.offs.resize(q + 1);
                         break;
@@ -706,7 +716,8 @@ size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
         if (data[i] == 0x01) {
             sb.seqs.append(data.data() + start, i - start);
             sb.offs.push_back(sb.seqs.size());
-            sb.ids.push_back("read_" + std::to_string(num_reads));
+            sb.own_ids.push_back("read_" + std::to_string(num_reads));
+            sb.ids.push_back(sb.own_ids.back());
             num_reads++;
             start = i + 1;
             if (sb.seqs.size() >= o.super_batch_chars) flush();

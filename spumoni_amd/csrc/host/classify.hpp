@@ -51,7 +51,9 @@ size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promot
 // FASTA/FASTQ driver (classify_reads_pml :845-1034, classify_reads_ms :1036-1217).
 // Writes <pattern>.pseudo_lengths | .lengths + .pointers, [.doc_numbers], [.report];
 // returns the number of reads processed.  Output order = input order (the reference's -t 1).
-size_t classify_reads(IndexSet& set, const RunOptions& o);
+// preloaded: the reads file, already mapped (while the index was loading); nullptr = map it here.
+class ReadFile;
+size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded = nullptr);
 // general-text driver (:1219-1297): reads separated by \x01, named read_<i>
 size_t classify_general_reads(IndexSet& set, const RunOptions& o);
 

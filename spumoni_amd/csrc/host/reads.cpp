@@ -1,11 +1,18 @@
 #include "reads.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
+#include <cstring>
 #include <stdexcept>
+#include <thread>
 
 namespace spumoni_host {
 
@@ -29,25 +36,59 @@ void fatal_warning(const char* fmt, ...) {  // FATAL_WARNING, include/spumoni_ma
     std::exit(1);
 }
 
-ReadFile::ReadFile(const std::string& path) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("cannot open " + path);
-    in.seekg(0, std::ios::end);
-    const std::streamoff sz = in.tellg();
-    in.seekg(0, std::ios::beg);
-    data_.resize((size_t)sz);
-    if (sz > 0) in.read(&data_[0], sz);
-    // line table (std::getline semantics: a trailing '\n' does not start another line)
-    size_t b = 0;
-    for (size_t i = 0; i < data_.size(); ++i) {
-        if (data_[i] == '\n') {
-            lines_.emplace_back(b, i);
-            b = i + 1;
-        }
+ReadFile::ReadFile(const std::string& path, unsigned threads) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (::fstat(fd, &st) != 0) {
+        ::close(fd);
+        throw std::runtime_error("cannot stat " + path);
     }
-    if (b < data_.size()) lines_.emplace_back(b, data_.size());
-    ends_with_newline_ = !data_.empty() && data_.back() == '\n';
-    if (data_.empty()) eof_ = true;
+    size_ = (size_t)st.st_size;
+    if (size_ > 0) {
+        void* p = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (p == MAP_FAILED) {
+            ::close(fd);
+            throw std::runtime_error("cannot map " + path);
+        }
+        data_ = (const char*)p;
+    }
+    ::close(fd);
+    // line table (std::getline semantics: a trailing '\n' does not start another line): every thread
+    // finds the newlines of its part of the file, the parts are then laid end to end
+    const unsigned nt = std::max(1u, std::min<unsigned>(threads, (unsigned)(size_ / (8u << 20)) + 1));
+    std::vector<std::vector<size_t>> part(nt);
+    auto scan = [&](unsigned t) {
+        const size_t lo = size_ * t / nt, hi = size_ * (t + 1) / nt;
+        std::vector<size_t>& v = part[t];
+        v.reserve((hi - lo) / 64 + 16);
+        const char* p = data_ + lo;
+        const char* const e = data_ + hi;
+        while (p < e) {
+            const char* q = (const char*)std::memchr(p, '\n', (size_t)(e - p));
+            if (!q) break;
+            v.push_back((size_t)(q - data_) + 1);  // the next line starts behind the newline
+            p = q + 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (auto& x : th) x.join();
+    size_t total = 1;
+    for (auto& v : part) total += v.size();
+    line_start_.reserve(total + 1);
+    line_start_.push_back(0);
+    for (auto& v : part) line_start_.insert(line_start_.end(), v.begin(), v.end());
+    ends_with_newline_ = size_ > 0 && data_[size_ - 1] == '\n';
+    // a file that does not end in a newline has one more line; either way the last entry is one past
+    // the (virtual) newline that ends the last line
+    if (size_ > 0 && !ends_with_newline_) line_start_.push_back(size_ + 1);
+    if (size_ == 0) eof_ = true;
+}
+
+ReadFile::~ReadFile() {
+    if (data_) ::munmap((void*)data_, size_);
 }
 
 bool ReadFile::next_batch(size_t num_bases, std::vector<ParsedRead>& out) {
@@ -63,7 +104,7 @@ bool ReadFile::next_batch(size_t num_bases, std::vector<ParsedRead>& out) {
 bool ReadFile::next_range(size_t num_bases, Range& out) {
     // input type sniffing (batch_loader.cpp:30-38)
     if (format_ == ReadFormat::NotClear) {
-        if (data_.empty()) return false;
+        if (size_ == 0) return false;
         switch (data_[0]) {
             case '>': format_ = ReadFormat::Fasta; break;
             case '@': format_ = ReadFormat::Fastq; break;
@@ -75,14 +116,14 @@ bool ReadFile::next_range(size_t num_bases, Range& out) {
     bool valid = false;
     const size_t first = next_line_;
     while (!eof_ && covered < num_bases) {
-        if (next_line_ >= lines_.size()) {
+        if (next_line_ >= line_count()) {
             // getline() fails: nothing left.  loadBatch returns false and the lines already
             // taken for this batch are dropped (FASTQ tail quirk, Appendix C16)
             eof_ = true;
             return false;
         }
-        const size_t len = lines_[next_line_].second - lines_[next_line_].first;
-        const bool last_line = next_line_ + 1 == lines_.size();
+        const size_t len = line_len(next_line_);
+        const bool last_line = next_line_ + 1 == line_count();
         next_line_++;
         nlines++;
         record += len;
@@ -109,8 +150,8 @@ bool ReadFile::next_range(size_t num_bases, Range& out) {
     if (!valid) return false;
     out.first = first;
     out.last = next_line_;
-    out.bytes = 0;
-    for (size_t i = first; i < next_line_; ++i) out.bytes += lines_[i].second - lines_[i].first;
+    // characters in those lines: the span minus one newline per line (the last line of the file may lack its own)
+    out.bytes = line_start_[next_line_] - line_start_[first] - (next_line_ - first);
     return true;
 }
 
@@ -139,30 +180,40 @@ void ReadFile::parse_range(const Range& r, std::vector<ParsedRead>& out, ParseEr
         size_t ws = hdr.find_first_of(" \t\r", 1);
         if (ws == std::string_view::npos) ws = hdr.size();
         ParsedRead rd;
-        rd.id.assign(hdr.substr(1, ws));  // count = ws: includes the whitespace character itself
+        rd.id = hdr.substr(1, ws);  // count = ws: includes the whitespace character itself
         if (format_ == ReadFormat::Fastq) {
             if (i >= last) return;
             std::string_view s = line(i++);
             strip_trailing_space(s);
-            rd.seq.assign(s);
+            rd.one = s;
             if (i >= last) return;  // '+' line
             i++;
             if (i >= last) return;  // qualities
             i++;
         } else {
             bool dropped = false;
+            size_t nseq = 0;  // sequence lines of this record
             for (;;) {
                 if (i >= last) {
                     // the reference peeks past the end, getline fails and it returns seq.size():
                     // a record with an empty sequence at the end of a batch is dropped
-                    if (rd.seq.empty()) dropped = true;
+                    if (rd.seq().empty()) dropped = true;
                     break;
                 }
                 std::string_view s = line(i);
                 if (!s.empty() && s[0] == '>') break;
                 i++;
                 strip_trailing_space(s);
-                rd.seq.append(s);
+                if (nseq == 0) {
+                    rd.one = s;  // the usual case: one line, no copy
+                } else {
+                    if (!rd.multi) {
+                        rd.multi = true;
+                        rd.joined.assign(rd.one);
+                    }
+                    rd.joined.append(s);
+                }
+                nseq++;
             }
             if (dropped) return;
         }

@@ -18,15 +18,23 @@ namespace spumoni_host {
 
 enum class ReadFormat { NotClear, Fasta, Fastq };
 
+// A read as views into the mapped reads file (no copies: 4 * 10^6 reads a second have to come out of
+// the parser); only a multi-line FASTA record owns a joined copy of its sequence.
 struct ParsedRead {
-    std::string id;   // header.substr(1, index of first whitespace)  -- keeps that whitespace (C6)
-    std::string seq;  // multi-line FASTA concatenated, trailing whitespace of each line stripped
+    std::string_view id;      // header.substr(1, index of first whitespace)  -- keeps that whitespace (C6)
+    std::string_view one;     // single-line sequence, trailing whitespace stripped
+    std::string joined;       // multi-line FASTA concatenated, trailing whitespace of each line stripped
+    bool multi = false;
+    std::string_view seq() const { return multi ? std::string_view(joined) : one; }
 };
 
 class ReadFile {
 public:
-    // Loads the file into memory; throws std::runtime_error if it cannot be read.
-    explicit ReadFile(const std::string& path);
+    // Maps the file and finds its lines (several threads); throws std::runtime_error if it cannot be read.
+    explicit ReadFile(const std::string& path, unsigned threads = 8);
+    ~ReadFile();
+    ReadFile(const ReadFile&) = delete;
+    ReadFile& operator=(const ReadFile&) = delete;
 
     // Next batch of the reference's loadBatch(input, num_bases) segmentation, parsed with
     // grabNextRead semantics.  Returns false when loadBatch would return false (end of
@@ -52,16 +60,17 @@ public:
     ReadFormat format() const { return format_; }
 
 private:
-    std::string data_;
-    std::vector<std::pair<size_t, size_t>> lines_;  // [begin, end) without the '\n'
+    const char* data_ = nullptr;  // the mapped file
+    size_t size_ = 0;
+    std::vector<size_t> line_start_;  // line i = [line_start_[i], line_start_[i + 1] - 1): one more entry than lines
     bool ends_with_newline_ = false;
     size_t next_line_ = 0;  // first line not yet consumed by a batch
     bool eof_ = false;      // the reference stream would no longer be good()
     ReadFormat format_ = ReadFormat::NotClear;
 
-    std::string_view line(size_t i) const {
-        return std::string_view(data_).substr(lines_[i].first, lines_[i].second - lines_[i].first);
-    }
+    size_t line_count() const { return line_start_.size() - 1; }
+    size_t line_len(size_t i) const { return line_start_[i + 1] - 1 - line_start_[i]; }
+    std::string_view line(size_t i) const { return std::string_view(data_ + line_start_[i], line_len(i)); }
 };
 
 // error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -184,7 +185,21 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     IndexSet set;
     STATUS_LOG(o.ms ? "ms_construct" : "pml_construct", o.ms ? "loading the MS index" : "loading the PML index");
     auto start_time = std::chrono::system_clock::now();
+    // the reads file is mapped and its lines are indexed on another thread while the index loads
+    std::unique_ptr<ReadFile> reads;
+    std::string reads_err;
+    std::thread reads_loader;
+    if (!o.is_general_text)
+        reads_loader = std::thread([&] {
+            try {
+                reads.reset(new ReadFile(o.pattern_file, (unsigned)o.format_threads));
+            } catch (const std::exception& e) {
+                reads_err = e.what();
+            }
+        });
     set.load(o);
+    if (reads_loader.joinable()) reads_loader.join();
+    if (!reads_err.empty()) fatal_error("%s", reads_err.c_str());
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     std::cout << std::endl;
     if (o.use_promotions)
@@ -218,7 +233,7 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     }
     start_time = std::chrono::system_clock::now();
     STATUS_LOG(tag, o.ms ? "processing the reads" : "processing the patterns");
-    size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o);
+    size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o, reads.get());
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     FORCE_LOG(tag, "finished processing %d reads. results are saved in *.%s file.", (int)num_reads,
               o.ms ? "lengths" : "pseudo_lengths");
@@ -258,7 +273,10 @@ static int dump_reads_main(int argc, char** argv) {
     size_t nb = 0;
     while (in.next_batch(1000, batch)) {
         std::printf("#batch %zu\n", nb++);
-        for (auto& rd : batch) std::printf("%s\t%s\n", rd.id.c_str(), rd.seq.c_str());
+        for (auto& rd : batch) {
+            const std::string_view sq = rd.seq();
+            std::printf("%.*s\t%.*s\n", (int)rd.id.size(), rd.id.data(), (int)sq.size(), sq.data());
+        }
     }
     return 0;
 }

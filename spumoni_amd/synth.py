@@ -382,7 +382,7 @@ def sample_reads(text: np.ndarray, nreads: int, length: int, seed: int, err: flo
 
 
 def simulate_reads(raw: RawIndex, nreads: int, length: int, seed: int,
-                   positive_fraction: float = 0.5, f_mis: float = 0.02):
+                   positive_fraction: float = 0.5, f_mis: float = 0.02, warmup: int = 0):
     """Reads for a statistical RLBWT (no text exists to sample from).
 
     "Positive" reads are produced by *simulating the backward search itself*
@@ -393,6 +393,14 @@ def simulate_reads(raw: RawIndex, nreads: int, length: int, seed: int,
     (compute_ms_pml.cpp:251-278).  The remaining reads are uniform over the
     letters.  Requires thresholds that satisfy thr[k] <= start[k] (true for
     `statistical_rlbwt` and for real indexes).
+
+    warmup: every search starts at pos = n - 1 (compute_ms_pml.cpp:243), so positive reads
+    simulated from there all spell the SAME path until their first mismatch (with f_mis = 0.02
+    and 44 characters, 41 % of them are the same read, and the walks of the others share their
+    first ~50 gathers: cache hits that no real batch of reads would see).  The first `warmup`
+    searched characters (the read's right end) are therefore drawn at random -- each sends the
+    walk to another letter's runs -- so that after them the walks of different reads are spread
+    over the whole index (sigma^warmup places) before the matching stretch begins.
 
     Runs on raw.heads.device.  Returns (seqs u8 [nreads*length], offsets i64).
     """
@@ -426,6 +434,8 @@ def simulate_reads(raw: RawIndex, nreads: int, length: int, seed: int,
             head = h64[k]
             rnd = letters[torch.randint(0, nl, (npos,), generator=g, device=dev)]
             mis = (torch.rand(npos, generator=g, device=dev) < f_mis) | (head <= TERMINATOR) | at_end
+            if i < warmup:
+                mis = torch.ones_like(mis)
             c = torch.where(mis, rnd, head)
             out[:, length - 1 - i] = c.to(torch.uint8)
             stay = (c == head) & ~at_end
