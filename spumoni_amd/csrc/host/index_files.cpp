@@ -276,6 +276,55 @@ bool read_wt_huff(Cursor& c, std::vector<uint8_t>& seq) {
 
 }  // namespace
 
+// Decodes ONE third-party stream and prints what the readers above make of it (`spumoni dump-sdsl`):
+// lets tests feed the readers byte strings derived by hand from the sdsl-lite / r-index sources'
+// serialize() functions (tests/test_sdsl_golden.py) instead of round-tripping our own writer.
+bool dump_sdsl_stream(const std::string& kind, const std::string& path, std::string& text, std::string& err) {
+    std::vector<uint8_t> raw;
+    if (!read_whole_file(path, raw)) {
+        err = "cannot read " + path;
+        return false;
+    }
+    Cursor c{raw};
+    text.clear();
+    auto done = [&](bool ok) {
+        if (!ok) err = "unexpected layout in the " + kind + " stream";
+        else if (c.p != raw.size()) {
+            err = "trailing bytes after the " + kind + " stream";
+            ok = false;
+        }
+        return ok;
+    };
+    if (kind == "int_vector") {
+        std::vector<uint64_t> v;
+        if (!read_int_vector(c, v)) return done(false);
+        for (uint64_t x : v) text += std::to_string(x) + " ";
+        return done(true);
+    }
+    if (kind == "bit_vector") {
+        BitVec b;
+        if (!read_bit_vector(c, b)) return done(false);
+        for (uint64_t i = 0; i < b.bits; ++i) text += b.get(i) ? '1' : '0';
+        return done(true);
+    }
+    if (kind == "sparse_sd") {
+        std::vector<uint64_t> ones;
+        uint64_t u = 0;
+        if (!read_sparse_sd(c, ones, u)) return done(false);
+        text = "u " + std::to_string(u) + " ones";
+        for (uint64_t x : ones) text += " " + std::to_string(x);
+        return done(true);
+    }
+    if (kind == "wt_huff") {
+        std::vector<uint8_t> seq;
+        if (!read_wt_huff(c, seq)) return done(false);
+        for (uint8_t x : seq) text += std::to_string((unsigned)x) + " ";
+        return done(true);
+    }
+    err = "unknown stream kind " + kind;
+    return false;
+}
+
 bool load_serialized_index(const std::string& path, bool is_ms, RawIndex& out, std::string& err) {
     std::vector<uint8_t> raw;
     if (!read_whole_file(path, raw)) {

@@ -41,5 +41,7 @@ bool read_whole_file(const std::string& path, std::vector<uint8_t>& out);
 // nor such a file is available offline; a structural mismatch is reported as an
 // error, never guessed around.  The result is the raw per-run arrays.
 bool load_serialized_index(const std::string& path, bool is_ms, RawIndex& out, std::string& err);
+// one third-party stream (kind: int_vector | bit_vector | sparse_sd | wt_huff) decoded to text: test hook
+bool dump_sdsl_stream(const std::string& kind, const std::string& path, std::string& text, std::string& err);
 
 }  // namespace spumoni_host

@@ -308,6 +308,18 @@ static int dump_index_main(int argc, char** argv) {
     return 0;
 }
 
+// debugging aid used by the CPU tests: decode one sdsl / r-index stream
+static int dump_sdsl_main(int argc, char** argv) {
+    if (argc < 3) return 1;
+    std::string text, err;
+    if (!dump_sdsl_stream(argv[1], argv[2], text, err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    std::printf("%s\n", text.c_str());
+    return 0;
+}
+
 static int spumoni_usage() {
     std::fprintf(stderr, "SPUMONI has different sub-commands to run which can used as follows:\n");
     std::fprintf(stderr, "Usage: spumoni <command> [options]\n\n");
@@ -320,6 +332,7 @@ static int spumoni_usage() {
 int main(int argc, char** argv) {
     if (argc > 2 && std::strcmp(argv[1], "dump-reads") == 0) return dump_reads_main(argc - 1, argv + 1);
     if (argc > 3 && std::strcmp(argv[1], "dump-index") == 0) return dump_index_main(argc - 1, argv + 1);
+    if (argc > 3 && std::strcmp(argv[1], "dump-sdsl") == 0) return dump_sdsl_main(argc - 1, argv + 1);
     std::fprintf(stderr, "\n\033[1m\033[31mSPUMONI version: %s \033[0m\n\n", SPUMONI_VERSION);
     if (argc > 1) {
         if (std::strcmp(argv[1], "build") == 0)

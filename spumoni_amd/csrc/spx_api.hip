@@ -648,7 +648,11 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         args.max_value_thr = max_value_thr;
         args.counters = ix->counters;
         args.narrow = width == 2 ? 1 : 0;
-        if ((rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK) return rc;
+        {  // a chunk of few, long reads is cut further and walked chunk-wise (spx_walk.hip)
+            bool chunked = false;
+            if ((rc = launch_walk_chunked(ix, mode, args, b - a, s_k, &chunked, a)) != SPX_OK) return rc;
+            if (!chunked && (rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK) return rc;
+        }
         if (mode == SPX_MODE_MS && dlen) {
             args.out_class = dcls ? (spx_class*)dcls + q0 : nullptr;
             if ((rc = launch_ms_extend(ix, args, s_k)) != SPX_OK) return rc;

@@ -834,19 +834,29 @@ __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* base, uint64_
     return v;
 }
 
-__global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const BatchArgs b) {
-    const uint64_t rd = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
-    if (rd >= b.nreads) return;
-    const uint64_t base = b.offs[rd];
-    const uint64_t m = b.offs[rd + 1] - base;
-    uint32_t* out = b.out_lengths + base;
+// Pointers reach the lanes through LDS.  A lane that reads its own read's pointers straight from memory touches
+// one 128-byte line per load and uses 16 bytes of it before the other wavefronts of the CU have pushed the line out
+// of the caches again: the pointers alone moved 8 x their size.  Here a wavefront loads a tile of EXT_PT pointers
+// for each of its 64 reads cooperatively -- 16 consecutive lanes take 16 consecutive pointers of one read, one
+// line -- and every lane then takes its own column of the tile from LDS.
+constexpr int EXT_TPB = 64;  // one wavefront per block: __syncthreads() is a wavefront barrier
+constexpr int EXT_PT = 16;   // pointers per read and tile
+
+__global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const BatchArgs b) {
+    __shared__ uint64_t s_ptr[EXT_PT][EXT_TPB + 1];
+    __shared__ uint64_t s_at[EXT_TPB];   // where each lane's tile starts in out_pointers
+    __shared__ uint32_t s_cnt[EXT_TPB];  // pointers of the tile that exist
+    const uint32_t lane = threadIdx.x;
+    const uint64_t rd = blockIdx.x * (uint64_t)EXT_TPB + lane;
+    const bool live = rd < b.nreads;
+    const uint64_t base = live ? b.offs[rd] : 0;
+    const uint64_t m = live ? b.offs[rd + 1] - base : 0;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);  // b.narrow: 16-bit lengths
     const uint8_t* text = ix.text;
     const uint64_t n = ix.n_text;
     const bool want_class = b.out_class != nullptr;
     uint64_t l = 0, prev = 0;
-    uint64_t ob_lo = 0, ob_hi = 0;         // staged lengths (u16) of the aligned group of 8
-    uint64_t pc0 = 0, pc1 = 0;             // pointers of the aligned pair holding index i
+    uint64_t ob_lo = 0, ob_hi = 0;  // staged lengths (u16) of the aligned group of 8
     const bool staged = m < 65536;
     // classifier over ascending indices
     const uint64_t w = b.bin_width ? b.bin_width : 1;
@@ -855,56 +865,66 @@ __global__ void __launch_bounds__(WALK_TPB) k_ms_extend(const DevIndex ix, const
     uint64_t bin_idx = 0;
     uint32_t bin_max = 0, above = 0, below = 0;
     uint64_t sum_max = 0;
-    for (uint64_t i = 0; i < m; ++i) {
-        // pointers are fetched two at a time (one aligned 16-byte load per pair)
-        const uint64_t gi = base + i;
-        if ((gi & 1) == 0 && i + 1 == m) {
-            pc0 = b.out_pointers[gi];  // the read's last pointer at an even index: its pair would lie past the buffer
-        } else if ((gi & 1) == 0 || i == 0) {
-            const ulonglong2 pp = *reinterpret_cast<const ulonglong2*>(b.out_pointers + (gi & ~1ull));
-            pc0 = pp.x;
-            pc1 = pp.y;
-        }
-        const uint64_t pos = (gi & 1) ? pc1 : pc0;
-        const bool cont = (i >= 1) && (pos == prev + 1);  // (i < 1 || pos != pointers[i-1] + 1)
-        if (!cont) {
-            // while (i+l < m && pos+l < n && read[i+l] == text[pos+l]) ++l;   unsigned arithmetic
-            // as upstream: pos + l may wrap for wrapped pointers (Appendix C3)
-            for (;;) {
-                const uint64_t ti = pos + l;
-                if (i + l >= m || ti >= n) break;
-                uint64_t lim = m - (i + l);
-                if (n - ti < lim) lim = n - ti;
-                const uint64_t x = load8_unaligned(b.seqs, base + i + l) ^ load8_unaligned(text, ti);
-                const uint64_t eq = x ? (uint64_t)(__builtin_ctzll(x) >> 3) : 8;  // equal leading bytes
-                const uint64_t adv = eq < lim ? eq : lim;  // never past the end of the read / text
-                l += adv;
-                if (adv < 8) break;  // mismatch, or an end reached inside this word
-            }
-        }
-        if (b.narrow)
-            out16[gi] = (uint16_t)l;
-        else if (staged)
-            stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, gi, i + 1 == m, base);
-        else
-            out[i] = (uint32_t)l;
-        if (want_class) {
-            if (i >= bin_hi) {
-                if (bin_max >= b.max_value_thr)
-                    above++;
-                else
-                    below++;
-                sum_max += bin_max;
-                bin_max = 0;
-                bin_idx++;
-                bin_hi = (bin_idx + 1 == nb) ? m : bin_hi + w;
-            }
-            bin_max = (uint32_t)l > bin_max ? (uint32_t)l : bin_max;
-        }
-        l = (l == 0 ? 0 : (l - 1));
-        prev = pos;
+    uint64_t mmax = m;  // the wavefront's longest read
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const uint64_t o = __shfl_xor(mmax, sft);
+        mmax = o > mmax ? o : mmax;
     }
-    if (want_class) {
+    for (uint64_t i0 = 0; i0 < mmax; i0 += EXT_PT) {
+        __syncthreads();  // the tile before this one has been used up
+        s_at[lane] = base + i0;
+        s_cnt[lane] = i0 < m ? (uint32_t)(m - i0 < EXT_PT ? m - i0 : EXT_PT) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < EXT_TPB * EXT_PT / EXT_TPB; ++p) {  // 16 passes of 4 reads x 16 pointers
+            const uint32_t R = (uint32_t)p * (EXT_TPB / EXT_PT) + (lane >> 4), j = lane & (EXT_PT - 1);
+            if (j < s_cnt[R]) s_ptr[j][R] = b.out_pointers[s_at[R] + j];
+        }
+        __syncthreads();
+        const uint32_t cnt = s_cnt[lane];
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint64_t i = i0 + j, gi = base + i;
+            const uint64_t pos = s_ptr[j][lane];
+            const bool cont = (i >= 1) && (pos == prev + 1);  // (i < 1 || pos != pointers[i-1] + 1)
+            if (!cont) {
+                // while (i+l < m && pos+l < n && read[i+l] == text[pos+l]) ++l;   unsigned arithmetic
+                // as upstream: pos + l may wrap for wrapped pointers (Appendix C3)
+                for (;;) {
+                    const uint64_t ti = pos + l;
+                    if (i + l >= m || ti >= n) break;
+                    uint64_t lim = m - (i + l);
+                    if (n - ti < lim) lim = n - ti;
+                    const uint64_t x = load8_unaligned(b.seqs, base + i + l) ^ load8_unaligned(text, ti);
+                    const uint64_t eq = x ? (uint64_t)(__builtin_ctzll(x) >> 3) : 8;  // equal leading bytes
+                    const uint64_t adv = eq < lim ? eq : lim;  // never past the end of the read / text
+                    l += adv;
+                    if (adv < 8) break;  // mismatch, or an end reached inside this word
+                }
+            }
+            if (b.narrow)
+                out16[gi] = (uint16_t)l;
+            else if (staged)
+                stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, gi, i + 1 == m, base);
+            else
+                b.out_lengths[gi] = (uint32_t)l;
+            if (want_class) {
+                if (i >= bin_hi) {
+                    if (bin_max >= b.max_value_thr)
+                        above++;
+                    else
+                        below++;
+                    sum_max += bin_max;
+                    bin_max = 0;
+                    bin_idx++;
+                    bin_hi = (bin_idx + 1 == nb) ? m : bin_hi + w;
+                }
+                bin_max = (uint32_t)l > bin_max ? (uint32_t)l : bin_max;
+            }
+            l = (l == 0 ? 0 : (l - 1));
+            prev = pos;
+        }
+    }
+    if (want_class && live) {
         if (m > 0) {
             if (bin_max >= b.max_value_thr)
                 above++;
@@ -1218,8 +1238,10 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
 
 // Long-read batches (BASELINE config 5: 50 000 x 10 kbp, 6 250 per GPU): fewer reads than the chip has
 // lanes.  Cut them into chunks and walk the chunks (spx_internal.h).  *done = false: not such a batch.
+// gi_base: the batch's characters are seqs[gi_base, gi_base + total_chars) (offsets are absolute: a piece of a
+// larger host batch starts where the piece before it ended)
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
-                        bool* done) {
+                        bool* done, uint64_t gi_base) {
     *done = false;
     ix->last_chunk_len = ix->last_chunk_bound = 0;
     if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
@@ -1267,7 +1289,7 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     if ((rc = chunk_scratch(ix, 1, 2 * (bound + 1) * sizeof(WalkState), &p_ends)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 2, bound * sizeof(SeamRec), &p_seams)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 3, nck * sizeof(WalkState), &p_ckpt)) != SPX_OK) return rc;
-    if ((rc = chunk_scratch(ix, 4, total_chars + 16, &p_flags)) != SPX_OK) return rc;
+    if ((rc = chunk_scratch(ix, 4, total_chars + 32, &p_flags)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 5, fail_words * 4, &p_fail)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 6, (args.nreads + 2) * 8 * 3 + 16, &p_cnt)) != SPX_OK) return rc;
     if ((rc = chunk_scratch(ix, 7, cub_bytes + 256, &p_cub)) != SPX_OK) return rc;
@@ -1287,9 +1309,11 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     a.ch.desc = (const ChunkDesc*)p_desc;
     a.ch.nchunks = nchunks;
     a.ch.ends = (WalkState*)p_ends;
-    a.ch.ckpt = (WalkState*)p_ckpt;
+    a.ch.ckpt = (WalkState*)p_ckpt - (gi_base >> CKPT_SHIFT);  // indexed by character index >> CKPT_SHIFT
     a.ch.seams = (SeamRec*)p_seams;
-    a.ch.flags = (uint8_t*)p_flags;
+    // indexed by character index; flags are read and written in aligned groups of 8, so the origin is moved by a
+    // multiple of 8 and a group in front of the first character stays inside the buffer
+    a.ch.flags = (uint8_t*)p_flags + 8 - (gi_base & ~7ull);
     a.ch.read_fail = (uint32_t*)p_fail;
     a.ch.chunk_start = chunk_start;
     a.ch.reentry = (WalkState*)p_ends + (bound + 1);
@@ -1362,8 +1386,8 @@ int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stre
 }
 
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
-    const unsigned grid = (unsigned)((args.nreads + WALK_TPB - 1) / WALK_TPB);
-    k_ms_extend<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, args);
+    const unsigned grid = (unsigned)((args.nreads + EXT_TPB - 1) / EXT_TPB);
+    k_ms_extend<<<grid ? grid : 1, EXT_TPB, 0, stream>>>(ix->view, args);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }

@@ -145,3 +145,89 @@ def test_host_entry_points_pipeline_large_batches(oracle_mod):
     assert np.array_equal(ref_ms["pointers"][: offs[ns]], w["pointers"])
     assert np.array_equal(ref_ms["lengths"][: offs[ns]], w["lengths"])
     assert np.array_equal(ref_ms["docs"][: offs[ns]], w["docs"])
+
+
+def test_config4_scale_ms_doc(oracle_mod):
+    """BASELINE config[3] shape at scale: statistical index r = 2^27 with SA samples and 10 documents, 5 * 10^6
+    reads of 55 minimizer characters, MS pointers + document ids (MS lengths need a text, which a statistical
+    index does not have: test_config2 / the parity tests cover them).  Oracle on a 50 000-read sample, bit for
+    bit; the whole batch through partition invariance and the suffix property (the walk starts at a read's
+    right end, so pointers / documents of a read's suffix are the suffix of the read's)."""
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=5, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
+    nreads, m = 5_000_000, 55
+    seqs, offs = synth.simulate_reads(raw, nreads, m, seed=15, warmup=4)
+    ix = capi.Index.from_raw(raw, 0)
+    d_seqs = capi.pad_seqs(seqs)
+
+    def ms_dev(s, o):
+        n = s.numel()
+        d_ptr = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_doc = torch.empty(n + 8, dtype=torch.int32, device="cuda")
+        ix.query_device(capi.SPX_MODE_MS, capi.pad_seqs(s), o, n, d_pointers=d_ptr, d_docs=d_doc)
+        torch.cuda.synchronize()
+        ix.last_stats()
+        return d_ptr, d_doc[:n]
+
+    ptr, doc = ms_dev(seqs, offs)
+    ns = 50_000
+    rawc = raw.cpu()
+    del raw
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    w = orc.ms(seqs[: ns * m].cpu().numpy(), offs[: ns + 1].cpu().numpy(), want_docs=True)
+    assert np.array_equal(ptr[: ns * m].cpu().numpy().view(np.uint64), w["pointers"])
+    assert np.array_equal(doc[: ns * m].cpu().numpy().view(np.uint32), w["docs"])
+    # partition invariance, ragged split
+    k = 1_777_777
+    pa, da = ms_dev(seqs[: k * m], offs[: k + 1])
+    pb, db = ms_dev(seqs[k * m:], offs[k:] - offs[k])
+    assert torch.equal(torch.cat([pa, pb]), ptr) and torch.equal(torch.cat([da, db]), doc)
+    # suffix property on 200k reads cut at random positions
+    rng = np.random.default_rng(1)
+    nc = 200_000
+    cut = torch.from_numpy(rng.integers(1, m, size=nc)).cuda()
+    lens = m - cut
+    so = torch.zeros(nc + 1, dtype=torch.int64, device="cuda")
+    so[1:] = torch.cumsum(lens, 0)
+    pos = torch.arange(int(so[-1]), device="cuda")
+    rid = torch.searchsorted(so, pos, right=True) - 1
+    src = rid * m + cut[rid] + (pos - so[rid])
+    ps, ds = ms_dev(seqs[src], so)
+    assert torch.equal(ps, ptr[src]) and torch.equal(ds, doc[src])
+
+
+def test_config5_scale_long_reads_chunked(oracle_mod):
+    """BASELINE config[4] shape at scale: 50 000 reads of 2 200 minimizer characters (10 kbp at the digestion
+    density) and the per-GPU share of 6 250, statistical index r = 2^27.  Such batches take the chunked walk
+     on their own; it must equal the plain walk of the same batch bit for bit (the whole batch:
+    lengths and classes), and the oracle on a sample of whole reads."""
+    raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    ix = capi.Index.from_raw(raw, 0)
+    rawc = raw.cpu()
+    del raw
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    for nreads in (50_000, 6_250):
+        seqs, offs = synth.simulate_reads(_dev_raw(rawc), nreads, 2200, seed=16 + nreads, warmup=4)
+        ix.set_option("chunk_mode", 0)
+        got, cls = _pml_dev(ix, seqs, offs, classify=(150, 5))
+        cs = ix.last_chunk_stats()
+        assert cs["chunk_len"] >= 128, "a long-read batch must take the chunked walk"
+        assert cs["fallback_reads"] <= nreads // 1000
+        ix.set_option("chunk_mode", 1)  # never: the plain walk
+        want, wcls = _pml_dev(ix, seqs, offs, classify=(150, 5))
+        assert ix.last_chunk_stats()["chunk_len"] == 0
+        assert torch.equal(got, want) and torch.equal(cls, wcls)
+        ns = 150
+        o = orc.pml(seqs[: ns * 2200].cpu().numpy(), offs[: ns + 1].cpu().numpy())
+        assert np.array_equal(got[: ns * 2200].cpu().numpy().view(np.uint32), o)
+    ix.set_option("chunk_mode", 0)
+
+
+def _dev_raw(rawc):
+    """the raw arrays back on the device (simulate_reads runs where they live)"""
+    kw = {}
+    import dataclasses
+
+    for f in dataclasses.fields(rawc):
+        v = getattr(rawc, f.name)
+        kw[f.name] = v.cuda() if isinstance(v, torch.Tensor) else v
+    return synth.RawIndex(**kw)

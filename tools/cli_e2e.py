@@ -52,11 +52,12 @@ def run(tag, reads, extra_env):
     err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
     assert r.returncode == 0, err
     n = nreads if reads.endswith("reads.fa") else ncpu
-    load = [l for l in err.splitlines() if "loading the PML index" in l]
-    proc = [l for l in err.splitlines() if "processing the patterns" in l]
-    print(f"== {tag}: {dt:.2f}s wall, {n/dt/1e6:.2f} M reads/s end to end "
+    import re
+    secs = [float(x) for x in re.findall(r"done\.\s+\(([0-9.]+) sec\)", err)]  # index load, processing the patterns
+    load_s, proc_s = (secs + [0, 0])[:2]
+    print(f"== {tag}: {dt:.2f}s wall (process start to exit), {n/dt/1e6:.2f} M reads/s end to end; "
+          f"loading the index {load_s:.3f}s, processing the patterns {proc_s:.3f}s = {n/max(proc_s,1e-9)/1e6:.2f} M reads/s "
           f"(pseudo_lengths {os.path.getsize(reads + '.pseudo_lengths')/1e6:.0f} MB)")
-    print("   ", (load + [""])[0].strip(), "|", (proc + [""])[0].strip())
     for l in err.splitlines():
         if "[timing]" in l:
             print("   ", l.strip())
