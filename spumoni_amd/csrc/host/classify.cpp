@@ -236,6 +236,10 @@ struct SuperBatch {
 
 struct Results {
     PinnedBuf<uint32_t> lengths, docs;
+    // reads shorter than 65536 characters: lengths and document ids come back as 16-bit values (half the
+    // bytes over PCIe, half the store instructions in the walk); `narrow` says which pair of buffers holds them
+    PinnedBuf<uint16_t> lengths16, docs16;
+    bool narrow = false;
     PinnedBuf<uint64_t> pointers;
     PinnedBuf<spx_class> cls;
     // results of read q are entries [beg[q], end[q]) of the arrays above: the read's own
@@ -254,18 +258,32 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     // with digestion the results are laid out at the digested offsets, inside a region as large as
     // the worst case (every k-mer reported: 1 byte each for -m, k letters for -a)
     const uint64_t grow = digest && o.use_dna_letters ? (uint64_t)o.k : 1;
-    res.lengths.resize_uninit(total * grow);
+    uint64_t longest = 0;
+    for (size_t q = 0; q < nreads; ++q) longest = std::max<uint64_t>(longest, sb.offs[q + 1] - sb.offs[q]);
+    res.narrow = !digest && longest < 65536;
+    if (res.narrow) {
+        res.lengths16.resize_uninit(total + 8);
+        if (o.use_doc) res.docs16.resize_uninit(total + 8);
+    } else {
+        res.lengths.resize_uninit(total * grow);
+        if (o.use_doc) res.docs.resize_uninit(total * grow);
+    }
     if (o.ms) res.pointers.resize_uninit(total * grow);
-    if (o.use_doc) res.docs.resize_uninit(total * grow);
     if (o.write_report) res.cls.resize_uninit(nreads);
     res.beg.resize(nreads);
     res.end.resize(nreads);
     int rc;
     if (!digest) {
-        rc = spx_query_batch(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
-                             res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
-                             o.use_doc ? res.docs.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
-                             o.bin_size, max_value_thr);
+        if (res.narrow)
+            rc = spx_query_batch16(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
+                                   res.lengths16.data(), o.ms ? res.pointers.data() : nullptr,
+                                   o.use_doc ? res.docs16.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
+                                   o.bin_size, max_value_thr);
+        else
+            rc = spx_query_batch(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
+                                 res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
+                                 o.use_doc ? res.docs.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
+                                 o.bin_size, max_value_thr);
         for (size_t q = 0; q < nreads; ++q) {
             res.beg[q] = sb.offs[q];
             res.end[q] = sb.offs[q + 1];
@@ -339,11 +357,17 @@ void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res,
         const uint64_t a = res.beg[q], b = res.end[q];
         if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
             out.td.header(sb.ids[q]);
-            out.td.values(res.docs.data() + a, b - a);
+            if (res.narrow)
+                out.td.values(res.docs16.data() + a, b - a);
+            else
+                out.td.values(res.docs.data() + a, b - a);
         }
         if (!o.report_only) {
             out.tl.header(sb.ids[q]);  // :1008-1010
-            out.tl.values(res.lengths.data() + a, b - a);
+            if (res.narrow)
+                out.tl.values(res.lengths16.data() + a, b - a);
+            else
+                out.tl.values(res.lengths.data() + a, b - a);
         }
         if (o.ms) {  // :1190-1195
             out.tp.header(sb.ids[q]);

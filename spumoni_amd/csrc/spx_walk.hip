@@ -90,69 +90,146 @@ __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t
     offp = t ? off - prev : LFoff + off;
 }
 
-// Output staging: values < 65536 of the aligned group of 8 outputs [g8, g8+8) are collected
-// as u16 in two registers while the walk descends and written as two 16-byte stores when
-// the group is complete (one full 32-byte sector); groups cut by the read's ends fall back
-// to scalar stores of the covered elements.
+// Output staging.  A lane's stores go to its own read: 64 lanes, 64 different cache lines per store
+// instruction, the same price in the memory pipeline as a gather (round 2: the walk without its length
+// stores ran 13.0 -> 10.0 ms).  So values are collected eight at a time -- elements [xi & ~7, xi | 7] of
+// the READ, as u16 in two registers -- and written with as few instructions as the group allows when
+// its lowest element has been produced.  Groups are aligned to the read, not to memory: only the read's
+// top group can be incomplete (round 1 aligned them to memory, which left a ragged group at BOTH ends of
+// every read and scalar stores for each of its elements: 16 store instructions per 44-character read,
+// now 11; with 16-bit outputs 6).  The vector stores are therefore only element-aligned, which gfx950
+// global stores take.  (It made no difference to the time; nor did 32 values per lane through LDS and
+// 64 / 128 contiguous bytes per flush, which was slower: profiles/r02_store_experiments.txt.)
+struct __attribute__((packed, aligned(4))) U32x4 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(4))) U32x2 {
+    uint32_t x, y;
+};
+struct __attribute__((packed, aligned(2))) H16x8 {
+    uint64_t lo, hi;
+};
+struct __attribute__((packed, aligned(2))) H16x4 {
+    uint64_t v;
+};
+struct __attribute__((packed, aligned(2))) H16x2 {
+    uint32_t v;
+};
+struct __attribute__((packed, aligned(8))) P64x2 {
+    uint64_t x, y;
+};
+__device__ __forceinline__ U32x4 widen4(uint64_t w) {
+    return U32x4{(uint32_t)w & 0xffff, (uint32_t)(w >> 16) & 0xffff, (uint32_t)(w >> 32) & 0xffff, (uint32_t)(w >> 48)};
+}
+
+// 32-bit outputs; m = elements of the read (or chunk), xi = element just produced (descending)
 __device__ __forceinline__ void stage8(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out,
-                                       uint64_t gi, uint32_t xi, uint64_t base, uint32_t m) {
-    const uint32_t slot = (uint32_t)gi & 7;
-    const uint64_t v = (uint64_t)value << ((slot & 3) * 16);
-    if (slot & 4)
-        hi |= v;
-    else
-        lo |= v;
-    if (slot == 0 || xi == 0) {
-        const uint64_t g8 = gi & ~7ull;
-        uint32_t* o = out + g8;
-        const bool full_lo = (g8 >= base) && (g8 + 3 < base + m);
-        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 < base + m);
-        if (full_lo)
-            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo & 0xffff, (uint32_t)(lo >> 16) & 0xffff,
-                                                      (uint32_t)(lo >> 32) & 0xffff, (uint32_t)(lo >> 48));
-        if (full_hi)
-            *reinterpret_cast<uint4*>(o + 4) = make_uint4((uint32_t)hi & 0xffff, (uint32_t)(hi >> 16) & 0xffff,
-                                                          (uint32_t)(hi >> 32) & 0xffff, (uint32_t)(hi >> 48));
-        if (!full_lo || !full_hi) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bool covered = t < 4 ? full_lo : full_hi;
-                const uint64_t gt = g8 + t;
-                if (!covered && gt >= gi && gt < base + m) {
-                    const uint64_t wv = t < 4 ? lo : hi;
-                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
-                }
+                                       uint64_t base, uint32_t xi, uint32_t m) {
+    const uint32_t slot = xi & 7;
+    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
+    lo |= (slot & 4) ? 0ull : v;
+    hi |= (slot & 4) ? v : 0ull;
+    if (slot == 0) {
+#ifdef SPX_EXP_WRSAME
+        uint32_t* o = out + ((base + xi) & 0x3ffffull);  // experiment: every store lands in one hot megabyte
+#else
+        uint32_t* o = out + base + xi;
+#endif
+        const uint32_t cnt = m - xi;  // >= 8 for every group but the read's top one
+        if (cnt >= 8) {
+            *reinterpret_cast<U32x4*>(o) = widen4(lo);
+            *reinterpret_cast<U32x4*>(o + 4) = widen4(hi);
+        } else {
+            uint64_t src = lo;
+            if (cnt & 4) {
+                *reinterpret_cast<U32x4*>(o) = widen4(lo);
+                src = hi;
+                o += 4;
             }
+            if (cnt & 2) {
+                *reinterpret_cast<U32x2*>(o) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
+                src >>= 32;
+                o += 2;
+            }
+            if (cnt & 1) *o = (uint32_t)src & 0xffff;
         }
         lo = hi = 0;
     }
 }
 
-// The same for 16-bit outputs: the two staging registers ARE the eight u16 values, one
-// 16-byte store per complete group.
-__device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t value, uint16_t* out, uint64_t gi,
-                                        uint32_t xi, uint64_t base, uint32_t m) {
-    const uint32_t slot = (uint32_t)gi & 7;
+// The same for 16-bit outputs: the two staging registers ARE the eight u16 values, one 16-byte
+// store per complete group.
+__device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t value, uint16_t* out, uint64_t base,
+                                        uint32_t xi, uint32_t m) {
+    const uint32_t slot = xi & 7;
     const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
-    if (slot & 4)
-        hi |= v;
-    else
-        lo |= v;
-    if (slot == 0 || xi == 0) {
-        const uint64_t g8 = gi & ~7ull;
-        uint16_t* o = out + g8;
-        if (g8 >= base && g8 + 7 < base + m) {
-            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    lo |= (slot & 4) ? 0ull : v;
+    hi |= (slot & 4) ? v : 0ull;
+    if (slot == 0) {
+        uint16_t* o = out + base + xi;
+        const uint32_t cnt = m - xi;
+        if (cnt >= 8) {
+            *reinterpret_cast<H16x8*>(o) = H16x8{lo, hi};
         } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const uint64_t gt = g8 + t;
-                if (gt >= gi && gt < base + m) o[t] = (uint16_t)((t < 4 ? lo : hi) >> ((t & 3) * 16));
+            uint64_t src = lo;
+            if (cnt & 4) {
+                *reinterpret_cast<H16x4*>(o) = H16x4{lo};
+                src = hi;
+                o += 4;
             }
+            if (cnt & 2) {
+                *reinterpret_cast<H16x2*>(o) = H16x2{(uint32_t)src};
+                src >>= 32;
+                o += 2;
+            }
+            if (cnt & 1) *o = (uint16_t)src;
         }
         lo = hi = 0;
     }
 }
+
+#ifdef SPX_EXP_G16
+// experiment: sixteen 16-bit values per flush (one full 32-byte sector, two stores back to back)
+__device__ __forceinline__ void stage16n(uint64_t& a0, uint64_t& a1, uint64_t& a2, uint64_t& a3, uint32_t value,
+                                         uint16_t* out, uint64_t base, uint32_t xi, uint32_t m) {
+    const uint32_t idx = xi & 15, r = idx >> 2;
+    const uint64_t v = (uint64_t)(value & 0xffffu) << ((idx & 3) * 16);
+    a0 |= r == 0 ? v : 0ull;
+    a1 |= r == 1 ? v : 0ull;
+    a2 |= r == 2 ? v : 0ull;
+    a3 |= r == 3 ? v : 0ull;
+    if (idx == 0) {
+        uint16_t* o = out + base + xi;
+        const uint32_t cnt = m - xi;
+        if (cnt >= 16) {
+            *reinterpret_cast<H16x8*>(o) = H16x8{a0, a1};
+            *reinterpret_cast<H16x8*>(o + 8) = H16x8{a2, a3};
+        } else {
+            uint64_t lo = a0, hi = a1;
+            uint32_t c = cnt;
+            if (c & 8) {
+                *reinterpret_cast<H16x8*>(o) = H16x8{a0, a1};
+                lo = a2;
+                hi = a3;
+                o += 8;
+            }
+            uint64_t src = lo;
+            if (c & 4) {
+                *reinterpret_cast<H16x4*>(o) = H16x4{lo};
+                src = hi;
+                o += 4;
+            }
+            if (c & 2) {
+                *reinterpret_cast<H16x2*>(o) = H16x2{(uint32_t)src};
+                src >>= 32;
+                o += 2;
+            }
+            if (c & 1) *o = (uint16_t)src;
+        }
+        a0 = a1 = a2 = a3 = 0;
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
@@ -644,44 +721,59 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     else
                         b.out_docs[gi] = doc;
                 }
+#ifdef SPX_EXP_NOEMIT
+            } else if (false) {
+#else
             } else if (MODE == SPX_MODE_PML) {
+#endif
                 // lengths[m-i-1] = length   (:281)
+#ifdef SPX_EXP_G16
                 if (NARROW)
-                    stage8n(ob_lo, ob_hi, length, reinterpret_cast<uint16_t*>(b.out_lengths), gi, xi, base, m);
+                    stage16n(ob_lo, ob_hi, pb0, pb1, length, reinterpret_cast<uint16_t*>(b.out_lengths), base, xi, m);
+#else
+                if (NARROW)
+                    stage8n(ob_lo, ob_hi, length, reinterpret_cast<uint16_t*>(b.out_lengths), base, xi, m);
+#endif
                 else if (m < 65536)
-                    stage8(ob_lo, ob_hi, length, b.out_lengths, gi, xi, base, m);
+                    stage8(ob_lo, ob_hi, length, b.out_lengths, base, xi, m);
                 else
                     b.out_lengths[gi] = length;
+#ifdef SPX_EXP_NOEMIT
+            } else if (MODE == SPX_MODE_MS) {
+#else
             } else {
-                // ms_pointers[m-i-1] = sample   (:618), staged 4 at a time
-                const uint32_t slot = (uint32_t)gi & 3;
+#endif
+                // ms_pointers[m-i-1] = sample   (:618), staged 4 at a time: elements [xi & ~3, xi | 3] of the read
+                const uint32_t slot = xi & 3;
                 pb0 = slot == 0 ? sample : pb0;
                 pb1 = slot == 1 ? sample : pb1;
                 pb2 = slot == 2 ? sample : pb2;
                 pb3 = slot == 3 ? sample : pb3;
-                if (slot == 0 || xi == 0) {
-                    const uint64_t g4 = gi & ~3ull;
-                    uint64_t* o = b.out_pointers + g4;
-                    if (g4 >= base && g4 + 3 < base + m) {
-                        *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2(pb0, pb1);
-                        *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2(pb2, pb3);
+                if (slot == 0) {
+                    uint64_t* o = b.out_pointers + gi;
+                    const uint32_t cnt = m - xi;  // >= 4 for every group but the read's top one
+                    if (cnt >= 4) {
+                        *reinterpret_cast<P64x2*>(o) = P64x2{pb0, pb1};
+                        *reinterpret_cast<P64x2*>(o + 2) = P64x2{pb2, pb3};
                     } else {
-                        if (g4 + 0 >= gi && g4 + 0 < base + m) o[0] = pb0;
-                        if (g4 + 1 >= gi && g4 + 1 < base + m) o[1] = pb1;
-                        if (g4 + 2 >= gi && g4 + 2 < base + m) o[2] = pb2;
-                        if (g4 + 3 >= gi && g4 + 3 < base + m) o[3] = pb3;
+                        if (cnt & 2) *reinterpret_cast<P64x2*>(o) = P64x2{pb0, pb1};
+                        if (cnt & 1) o[cnt & 2] = (cnt & 2) ? pb2 : pb0;
                     }
                 }
             }
             if (DOC && CHUNK != 2) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
                 if (NARROW)
-                    stage8n(db_lo, db_hi, doc, reinterpret_cast<uint16_t*>(b.out_docs), gi, xi, base, m);
+                    stage8n(db_lo, db_hi, doc, reinterpret_cast<uint16_t*>(b.out_docs), base, xi, m);
                 else if (m < 65536)
-                    stage8(db_lo, db_hi, doc, b.out_docs, gi, xi, base, m);
+                    stage8(db_lo, db_hi, doc, b.out_docs, base, xi, m);
                 else
                     b.out_docs[gi] = doc;
             }
+#if defined(SPX_EXP_NOEMIT) || defined(SPX_EXP_NOCLASS)
+            if (false) {
+#else
             if (want_class) {
+#endif
                 if (xi < bin_lo) {  // crossed into the previous bin (descending index)
                     if (bin_max >= b.max_value_thr)
                         above++;
@@ -790,36 +882,33 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
 // One lane per read; `l` is carried exactly like the reference; characters are
 // compared eight at a time (two aligned 64-bit loads + funnel shift per side).
 // ---------------------------------------------------------------------------
-// ascending counterpart of stage8 (the extension walks a read left to right)
-__device__ __forceinline__ void stage8_up(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out,
-                                          uint64_t gi, bool last, uint64_t base) {
-    const uint32_t slot = (uint32_t)gi & 7;
-    const uint64_t v = (uint64_t)value << ((slot & 3) * 16);
-    if (slot & 4)
-        hi |= v;
-    else
-        lo |= v;
+// ascending counterpart of stage8 (the extension walks a read left to right): elements [i & ~7, i | 7] of
+// the read, written when the group's highest element -- or the read's last -- has been produced
+__device__ __forceinline__ void stage8_up(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out, uint64_t base,
+                                          uint32_t i, bool last) {
+    const uint32_t slot = i & 7;
+    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
+    lo |= (slot & 4) ? 0ull : v;
+    hi |= (slot & 4) ? v : 0ull;
     if (slot == 7 || last) {
-        const uint64_t g8 = gi & ~7ull;
-        uint32_t* o = out + g8;
-        const bool full_lo = (g8 >= base) && (g8 + 3 <= gi);
-        const bool full_hi = (g8 + 4 >= base) && (g8 + 7 <= gi);
-        if (full_lo)
-            *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)lo & 0xffff, (uint32_t)(lo >> 16) & 0xffff,
-                                                      (uint32_t)(lo >> 32) & 0xffff, (uint32_t)(lo >> 48));
-        if (full_hi)
-            *reinterpret_cast<uint4*>(o + 4) = make_uint4((uint32_t)hi & 0xffff, (uint32_t)(hi >> 16) & 0xffff,
-                                                          (uint32_t)(hi >> 32) & 0xffff, (uint32_t)(hi >> 48));
-        if (!full_lo || !full_hi) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bool covered = t < 4 ? full_lo : full_hi;
-                const uint64_t gt = g8 + t;
-                if (!covered && gt >= base && gt <= gi) {
-                    const uint64_t wv = t < 4 ? lo : hi;
-                    o[t] = (uint32_t)(wv >> ((t & 3) * 16)) & 0xffff;
-                }
+        uint32_t* o = out + base + (i - slot);
+        const uint32_t cnt = slot + 1;
+        if (cnt == 8) {
+            *reinterpret_cast<U32x4*>(o) = widen4(lo);
+            *reinterpret_cast<U32x4*>(o + 4) = widen4(hi);
+        } else {
+            uint64_t src = lo;
+            if (cnt & 4) {
+                *reinterpret_cast<U32x4*>(o) = widen4(lo);
+                src = hi;
+                o += 4;
             }
+            if (cnt & 2) {
+                *reinterpret_cast<U32x2*>(o) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
+                src >>= 32;
+                o += 2;
+            }
+            if (cnt & 1) *o = (uint32_t)src & 0xffff;
         }
         lo = hi = 0;
     }
@@ -904,7 +993,7 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
             if (b.narrow)
                 out16[gi] = (uint16_t)l;
             else if (staged)
-                stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, gi, i + 1 == m, base);
+                stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
             else
                 b.out_lengths[gi] = (uint32_t)l;
             if (want_class) {
