@@ -56,6 +56,14 @@ enum : uint32_t {
 };
 
 constexpr int WALK_TPB = 256;
+#ifndef SPX_LEN_G
+#define SPX_LEN_G 32
+#endif
+constexpr int LEN_G = SPX_LEN_G;  // PML lengths / document ids staged per flush
+#ifndef SPX_PTR_G
+#define SPX_PTR_G 8
+#endif
+constexpr int PTR_G = SPX_PTR_G;  // MS pointers staged per flush (64 bytes)
 
 struct __attribute__((packed, aligned(4))) V16 {  // 16 bytes at 4-byte alignment
     uint32_t x, y, z, w;
@@ -188,48 +196,72 @@ __device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t val
     }
 }
 
-#ifdef SPX_EXP_G16
-// experiment: sixteen 16-bit values per flush (one full 32-byte sector, two stores back to back)
-__device__ __forceinline__ void stage16n(uint64_t& a0, uint64_t& a1, uint64_t& a2, uint64_t& a3, uint32_t value,
-                                         uint16_t* out, uint64_t base, uint32_t xi, uint32_t m) {
-    const uint32_t idx = xi & 15, r = idx >> 2;
+// Lengths, G of them per flush (as u16 in G / 4 registers; the values of a read shorter than 65 536 characters
+// fit): written as 16-bit values (one 16-byte store per eight) or widened to 32 bits (two), back to back.  More per
+// flush means fewer, larger writes reaching DRAM: 12.8 / 12.25 / 12.0 ms at 8 / 16 / 32 values per flush (16-bit
+// outputs, profiles/r02_store_experiments.txt).
+template <int G>
+struct StageN {
+    uint64_t a[G / 4];
+};
+template <int G, bool NARROW_OUT>
+__device__ __forceinline__ void stage_n(StageN<G>& st, uint32_t value, uint32_t* out32, uint64_t base, uint32_t xi,
+                                        uint32_t m) {
+    const uint32_t idx = xi & (G - 1), r = idx >> 2;
     const uint64_t v = (uint64_t)(value & 0xffffu) << ((idx & 3) * 16);
-    a0 |= r == 0 ? v : 0ull;
-    a1 |= r == 1 ? v : 0ull;
-    a2 |= r == 2 ? v : 0ull;
-    a3 |= r == 3 ? v : 0ull;
+#pragma unroll
+    for (int j = 0; j < G / 4; ++j) st.a[j] |= (r == (uint32_t)j) ? v : 0ull;
     if (idx == 0) {
-        uint16_t* o = out + base + xi;
-        const uint32_t cnt = m - xi;
-        if (cnt >= 16) {
-            *reinterpret_cast<H16x8*>(o) = H16x8{a0, a1};
-            *reinterpret_cast<H16x8*>(o + 8) = H16x8{a2, a3};
-        } else {
-            uint64_t lo = a0, hi = a1;
-            uint32_t c = cnt;
-            if (c & 8) {
-                *reinterpret_cast<H16x8*>(o) = H16x8{a0, a1};
-                lo = a2;
-                hi = a3;
-                o += 8;
+        const uint32_t cnt = m - xi;  // >= G for every group but the read's top one
+#pragma unroll
+        for (int q = 0; q < G / 8; ++q) {
+            const uint64_t lo = st.a[2 * q], hi = st.a[2 * q + 1];
+            if (cnt > 8u * q) {
+                const uint32_t c = cnt - 8 * q;
+                if (NARROW_OUT) {
+                    uint16_t* p = reinterpret_cast<uint16_t*>(out32) + base + xi + 8 * q;
+                    if (c >= 8) {
+                        *reinterpret_cast<H16x8*>(p) = H16x8{lo, hi};
+                    } else {
+                        uint64_t src = lo;
+                        if (c & 4) {
+                            *reinterpret_cast<H16x4*>(p) = H16x4{lo};
+                            src = hi;
+                            p += 4;
+                        }
+                        if (c & 2) {
+                            *reinterpret_cast<H16x2*>(p) = H16x2{(uint32_t)src};
+                            src >>= 32;
+                            p += 2;
+                        }
+                        if (c & 1) *p = (uint16_t)src;
+                    }
+                } else {
+                    uint32_t* p = out32 + base + xi + 8 * q;
+                    if (c >= 8) {
+                        *reinterpret_cast<U32x4*>(p) = widen4(lo);
+                        *reinterpret_cast<U32x4*>(p + 4) = widen4(hi);
+                    } else {
+                        uint64_t src = lo;
+                        if (c & 4) {
+                            *reinterpret_cast<U32x4*>(p) = widen4(lo);
+                            src = hi;
+                            p += 4;
+                        }
+                        if (c & 2) {
+                            *reinterpret_cast<U32x2*>(p) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
+                            src >>= 32;
+                            p += 2;
+                        }
+                        if (c & 1) *p = (uint32_t)src & 0xffff;
+                    }
+                }
             }
-            uint64_t src = lo;
-            if (c & 4) {
-                *reinterpret_cast<H16x4*>(o) = H16x4{lo};
-                src = hi;
-                o += 4;
-            }
-            if (c & 2) {
-                *reinterpret_cast<H16x2*>(o) = H16x2{(uint32_t)src};
-                src >>= 32;
-                o += 2;
-            }
-            if (c & 1) *o = (uint16_t)src;
         }
-        a0 = a1 = a2 = a3 = 0;
+#pragma unroll
+        for (int j = 0; j < G / 4; ++j) st.a[j] = 0;
     }
 }
-#endif
 
 // ---------------------------------------------------------------------------
 // lane-per-read state machine
@@ -289,9 +321,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     __shared__ uint32_t s_win[8 * WALK_TPB];
     uint64_t wbase = 0;
 #define WIN_CHAR(wi) ((s_win[((wi) >> 2) * WALK_TPB + threadIdx.x] >> (((wi)&3) * 8)) & 0xffu)
-    // output staging (PML): 8 u16 values of the aligned group of 8 outputs
-    uint64_t ob_lo = 0, ob_hi = 0, db_lo = 0, db_hi = 0;
-    uint64_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;  // MS pointers of the aligned group of 4
+    // output staging (PML): u16 values of the current group of outputs
+    StageN<LEN_G> obn{}, dbn{};  // PML lengths, document ids
+    uint64_t pbs[PTR_G] = {};  // MS pointers of the current group
     // classifier
     uint32_t bin_lo = 0, bin_max = 0, above = 0, below = 0;
     uint64_t sum_max = 0;
@@ -533,7 +565,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     const uint64_t end4 = (base + m + 3) & ~3ull;  // window ends past the last character
                     wbase = end4 >= 32 ? end4 - 32 : 0;
                 }
-                ob_lo = ob_hi = db_lo = db_hi = 0;
                 fb = 0;
                 seen = 0;
                 if (CHUNK == 2) ph = P_START;
@@ -727,15 +758,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else if (MODE == SPX_MODE_PML) {
 #endif
                 // lengths[m-i-1] = length   (:281)
-#ifdef SPX_EXP_G16
-                if (NARROW)
-                    stage16n(ob_lo, ob_hi, pb0, pb1, length, reinterpret_cast<uint16_t*>(b.out_lengths), base, xi, m);
-#else
-                if (NARROW)
-                    stage8n(ob_lo, ob_hi, length, reinterpret_cast<uint16_t*>(b.out_lengths), base, xi, m);
-#endif
-                else if (m < 65536)
-                    stage8(ob_lo, ob_hi, length, b.out_lengths, base, xi, m);
+                if (NARROW || m < 65536)
+                    stage_n<LEN_G, NARROW>(obn, length, b.out_lengths, base, xi, m);
                 else
                     b.out_lengths[gi] = length;
 #ifdef SPX_EXP_NOEMIT
@@ -743,29 +767,25 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
 #else
             } else {
 #endif
-                // ms_pointers[m-i-1] = sample   (:618), staged 4 at a time: elements [xi & ~3, xi | 3] of the read
-                const uint32_t slot = xi & 3;
-                pb0 = slot == 0 ? sample : pb0;
-                pb1 = slot == 1 ? sample : pb1;
-                pb2 = slot == 2 ? sample : pb2;
-                pb3 = slot == 3 ? sample : pb3;
+                // ms_pointers[m-i-1] = sample   (:618), staged PTR_G at a time: elements [xi & ~(PTR_G-1), ...] of the read
+                const uint32_t slot = xi & (PTR_G - 1);
+#pragma unroll
+                for (int j = 0; j < PTR_G; ++j) pbs[j] = slot == (uint32_t)j ? sample : pbs[j];
                 if (slot == 0) {
                     uint64_t* o = b.out_pointers + gi;
-                    const uint32_t cnt = m - xi;  // >= 4 for every group but the read's top one
-                    if (cnt >= 4) {
-                        *reinterpret_cast<P64x2*>(o) = P64x2{pb0, pb1};
-                        *reinterpret_cast<P64x2*>(o + 2) = P64x2{pb2, pb3};
-                    } else {
-                        if (cnt & 2) *reinterpret_cast<P64x2*>(o) = P64x2{pb0, pb1};
-                        if (cnt & 1) o[cnt & 2] = (cnt & 2) ? pb2 : pb0;
+                    const uint32_t cnt = m - xi;  // >= PTR_G for every group but the read's top one
+#pragma unroll
+                    for (int q = 0; q < PTR_G / 2; ++q) {
+                        if (cnt >= 2u * q + 2)
+                            *reinterpret_cast<P64x2*>(o + 2 * q) = P64x2{pbs[2 * q], pbs[2 * q + 1]};
+                        else if (cnt == 2u * q + 1)
+                            o[2 * q] = pbs[2 * q];
                     }
                 }
             }
             if (DOC && CHUNK != 2) {  // doc_nums[m-i-1] = curr_doc_id   (:336 / :677); ids < 65536
-                if (NARROW)
-                    stage8n(db_lo, db_hi, doc, reinterpret_cast<uint16_t*>(b.out_docs), base, xi, m);
-                else if (m < 65536)
-                    stage8(db_lo, db_hi, doc, b.out_docs, base, xi, m);
+                if (NARROW || m < 65536)
+                    stage_n<LEN_G, NARROW>(dbn, doc, b.out_docs, base, xi, m);
                 else
                     b.out_docs[gi] = doc;
             }
