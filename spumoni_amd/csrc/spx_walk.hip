@@ -99,10 +99,10 @@ __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t
 }
 
 // Output staging.  A lane's stores go to its own read: 64 lanes, 64 different cache lines per store
-// instruction, the same price in the memory pipeline as a gather (round 2: the walk without its length
-// stores ran 13.0 -> 10.0 ms).  So values are collected eight at a time -- elements [xi & ~7, xi | 7] of
-// the READ, as u16 in two registers -- and written with as few instructions as the group allows when
-// its lowest element has been produced.  Groups are aligned to the read, not to memory: only the read's
+// instruction, and small scattered writes are expensive in DRAM (round 2: the walk without its length
+// stores ran 13.0 -> 10.0 ms, with all of them landing in one hot megabyte 11.1 ms).  So values are collected
+// in registers -- a group of consecutive elements of the READ, as u16 -- and written back to back, with as few
+// instructions as the group allows, when its lowest element has been produced.  Groups are aligned to the read, not to memory: only the read's
 // top group can be incomplete (round 1 aligned them to memory, which left a ragged group at BOTH ends of
 // every read and scalar stores for each of its elements: 16 store instructions per 44-character read,
 // now 11; with 16-bit outputs 6).  The vector stores are therefore only element-aligned, which gfx950
@@ -128,72 +128,6 @@ struct __attribute__((packed, aligned(8))) P64x2 {
 };
 __device__ __forceinline__ U32x4 widen4(uint64_t w) {
     return U32x4{(uint32_t)w & 0xffff, (uint32_t)(w >> 16) & 0xffff, (uint32_t)(w >> 32) & 0xffff, (uint32_t)(w >> 48)};
-}
-
-// 32-bit outputs; m = elements of the read (or chunk), xi = element just produced (descending)
-__device__ __forceinline__ void stage8(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out,
-                                       uint64_t base, uint32_t xi, uint32_t m) {
-    const uint32_t slot = xi & 7;
-    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
-    lo |= (slot & 4) ? 0ull : v;
-    hi |= (slot & 4) ? v : 0ull;
-    if (slot == 0) {
-#ifdef SPX_EXP_WRSAME
-        uint32_t* o = out + ((base + xi) & 0x3ffffull);  // experiment: every store lands in one hot megabyte
-#else
-        uint32_t* o = out + base + xi;
-#endif
-        const uint32_t cnt = m - xi;  // >= 8 for every group but the read's top one
-        if (cnt >= 8) {
-            *reinterpret_cast<U32x4*>(o) = widen4(lo);
-            *reinterpret_cast<U32x4*>(o + 4) = widen4(hi);
-        } else {
-            uint64_t src = lo;
-            if (cnt & 4) {
-                *reinterpret_cast<U32x4*>(o) = widen4(lo);
-                src = hi;
-                o += 4;
-            }
-            if (cnt & 2) {
-                *reinterpret_cast<U32x2*>(o) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
-                src >>= 32;
-                o += 2;
-            }
-            if (cnt & 1) *o = (uint32_t)src & 0xffff;
-        }
-        lo = hi = 0;
-    }
-}
-
-// The same for 16-bit outputs: the two staging registers ARE the eight u16 values, one 16-byte
-// store per complete group.
-__device__ __forceinline__ void stage8n(uint64_t& lo, uint64_t& hi, uint32_t value, uint16_t* out, uint64_t base,
-                                        uint32_t xi, uint32_t m) {
-    const uint32_t slot = xi & 7;
-    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
-    lo |= (slot & 4) ? 0ull : v;
-    hi |= (slot & 4) ? v : 0ull;
-    if (slot == 0) {
-        uint16_t* o = out + base + xi;
-        const uint32_t cnt = m - xi;
-        if (cnt >= 8) {
-            *reinterpret_cast<H16x8*>(o) = H16x8{lo, hi};
-        } else {
-            uint64_t src = lo;
-            if (cnt & 4) {
-                *reinterpret_cast<H16x4*>(o) = H16x4{lo};
-                src = hi;
-                o += 4;
-            }
-            if (cnt & 2) {
-                *reinterpret_cast<H16x2*>(o) = H16x2{(uint32_t)src};
-                src >>= 32;
-                o += 2;
-            }
-            if (cnt & 1) *o = (uint16_t)src;
-        }
-        lo = hi = 0;
-    }
 }
 
 // Lengths, G of them per flush (as u16 in G / 4 registers; the values of a read shorter than 65 536 characters
