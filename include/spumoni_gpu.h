@@ -136,7 +136,9 @@ int spx_index_describe(const spx_index *ix, char *buf, size_t cap);
  * nreads+1 offsets into seqs.  All outputs are laid out at the same offsets
  * (element i of read q at offsets[q]+i), and may be NULL when not wanted:
  *   out_lengths   PML lengths (PML mode) or MS lengths (MS mode, needs
- *                 spx_index_set_text; compute_ms_pml.cpp:800-810)
+ *                 spx_index_set_text; compute_ms_pml.cpp:800-810).  PML mode
+ *                 with out_lengths NULL and out_class given classifies without
+ *                 writing the per-character values (the report's columns only)
  *   out_pointers  MS pointers (MS mode only)
  *   out_docs      document ids (index must have been built with doc arrays)
  *   out_class     nreads entries, bin-max classifier over out_lengths' values

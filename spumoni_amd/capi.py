@@ -263,7 +263,7 @@ class Index:
         nreads = offs.size - 1
         tot = int(offs[-1]) if nreads > 0 else 0
         vt = np.uint16 if bits == 16 else np.uint32
-        lens = np.zeros(max(tot, 1) + 8, dtype=vt) if want_lengths else None
+        lens = np.zeros(max(tot, 1) + 8, dtype=vt) if want_lengths else None  # PML: None + classify = report only
         ptrs = np.zeros(max(tot, 1), dtype=np.uint64) if mode == SPX_MODE_MS else None
         docs = np.zeros(max(tot, 1) + 8, dtype=vt) if want_docs else None
         cls_ = np.zeros(max(nreads, 1), dtype=CLASS_DTYPE) if classify else None

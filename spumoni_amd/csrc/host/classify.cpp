@@ -274,14 +274,16 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     res.end.resize(nreads);
     int rc;
     if (!digest) {
+        // SPUMONI_REPORT_ONLY (PML): the per-character values are neither written nor copied back
+        const bool no_len = o.report_only && !o.ms && o.write_report;
         if (res.narrow)
             rc = spx_query_batch16(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
-                                   res.lengths16.data(), o.ms ? res.pointers.data() : nullptr,
+                                   no_len ? nullptr : res.lengths16.data(), o.ms ? res.pointers.data() : nullptr,
                                    o.use_doc ? res.docs16.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
                                    o.bin_size, max_value_thr);
         else
             rc = spx_query_batch(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
-                                 res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
+                                 no_len ? nullptr : res.lengths.data(), o.ms ? res.pointers.data() : nullptr,
                                  o.use_doc ? res.docs.data() : nullptr, o.write_report ? res.cls.data() : nullptr,
                                  o.bin_size, max_value_thr);
         for (size_t q = 0; q < nreads; ++q) {

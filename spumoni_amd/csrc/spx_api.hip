@@ -457,8 +457,8 @@ static int check_query(spx_index* ix, int mode, const void* seqs, const void* of
         set_error("mode must be SPX_MODE_PML or SPX_MODE_MS");
         return SPX_E_ARG;
     }
-    if (mode == SPX_MODE_PML && !out_lengths) {
-        set_error("PML mode needs out_lengths");
+    if (mode == SPX_MODE_PML && !out_lengths && !out_class) {
+        set_error("PML mode needs out_lengths (or out_class alone: classification without the per-character values)");
         return SPX_E_ARG;
     }
     if (mode == SPX_MODE_PML && out_pointers) {

@@ -696,7 +696,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else if (MODE == SPX_MODE_PML) {
 #endif
                 // lengths[m-i-1] = length   (:281)
-                if (NARROW || m < 65536)
+                // (out_lengths == NULL: classification only -- the walk then runs at the gather ceiling)
+                if (b.out_lengths == nullptr) {
+                } else if (NARROW || m < 65536)
                     stage_n<LEN_G, NARROW>(obn, length, b.out_lengths, base, xi, m);
                 else
                     b.out_lengths[gi] = length;
@@ -1292,6 +1294,7 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     *done = false;
     ix->last_chunk_len = ix->last_chunk_bound = 0;
     if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
+    if (mode == SPX_MODE_PML && args.out_lengths == nullptr) return SPX_OK;  // classification only: the plain walk
     if (ix->num_cus == 0) {
         hipDeviceProp_t prop;
         SPX_HIP(hipGetDeviceProperties(&prop, ix->device));

@@ -32,6 +32,9 @@ def _compare_all(oracle_mod, raw, text, seqs, offs, ix=None):
     assert np.array_equal(got["class"]["above"], a)
     assert np.array_equal(got["class"]["below"], b)
     assert np.array_equal(got["class"]["sum_max"], s)
+    # classification alone (no per-character values written): the same classes
+    only = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_lengths=False, classify=(7, 3))
+    assert "lengths" not in only and np.array_equal(only["class"], got["class"])
     # the 16-bit entry point: same values, half the bytes
     got16 = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(7, 3), bits=16)
     assert got16["lengths"].dtype == np.uint16 and np.array_equal(got16["lengths"], want)
