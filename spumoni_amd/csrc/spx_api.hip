@@ -2,11 +2,14 @@
 // No CPU fallback exists anywhere in this library: without a gfx950 device every
 // entry point that needs one returns SPX_E_NODEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include <memory>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "spx_internal.h"
@@ -788,7 +791,7 @@ struct SpxFileHeader {
     uint64_t device_bytes;
 };
 
-constexpr size_t STAGE = 64u << 20;
+constexpr size_t STAGE = 16u << 20;
 
 // file -> device through two page-locked staging buffers (read of chunk i+1 overlaps copy of chunk i)
 int read_to_device(FILE* f, uint64_t off, void* dst, uint64_t bytes, void* stage[2], hipStream_t st, hipEvent_t ev[2]) {
@@ -860,6 +863,74 @@ struct Staging {  // two pinned buffers + a stream + two events, released on sco
     }
 };
 
+// One array between a file and the device, in up to IO_THREADS slices: every slice has its own descriptor position,
+// staging buffers and stream (a single reader does 6-7 GB/s from tmpfs, PCIe takes several times that).
+constexpr int IO_THREADS = 4;
+// Page-locked staging is expensive to allocate and more so to release (seconds for a few hundred MB): the pool
+// (8 x 16 MB) is made once per process and kept; one save / load at a time uses it.
+struct IoPool {
+    Staging sg[IO_THREADS];
+    bool ready = false;
+    std::mutex mu;
+    int init() {
+        if (ready) return SPX_OK;
+        for (auto& g : sg) {
+            const int rc = g.init();
+            if (rc != SPX_OK) return rc;
+        }
+        ready = true;
+        return SPX_OK;
+    }
+};
+static IoPool& io_pool() {
+    static IoPool* p = new IoPool();  // never destroyed: the HIP runtime may be gone by the time statics are
+    return *p;
+}
+int transfer_array(IoPool& pool, const std::string& path, uint64_t off, void* dev, uint64_t bytes, bool to_device,
+                   int device) {
+    if (bytes == 0) return SPX_OK;
+    const int nt = bytes >= (256ull << 20) ? IO_THREADS : 1;
+    std::vector<int> rc(nt, SPX_OK);
+    std::vector<std::string> msg(nt);
+    auto work = [&](int t) {
+        const uint64_t lo = (bytes * t / nt) & ~4095ull, hi = t + 1 == nt ? bytes : (bytes * (t + 1) / nt) & ~4095ull;
+        auto run = [&]() -> int {
+            SPX_HIP(hipSetDevice(device));
+            Staging& sg = pool.sg[t];
+            int r = SPX_OK;
+            FILE* f = fopen(path.c_str(), to_device ? "rb" : "r+b");
+            if (!f) {
+                set_error("cannot open %s", path.c_str());
+                return SPX_E_IO;
+            }
+            if (to_device) {
+                r = read_to_device(f, off + lo, (char*)dev + lo, hi - lo, sg.stage, sg.st, sg.ev);
+                if (r == SPX_OK && hipStreamSynchronize(sg.st) != hipSuccess) r = SPX_E_HIP;
+            } else {
+                r = fseeko(f, (off_t)(off + lo), SEEK_SET) == 0 ? SPX_OK : SPX_E_IO;
+                if (r == SPX_OK) r = write_from_device(f, (const char*)dev + lo, hi - lo, sg.stage, sg.st, sg.ev);
+            }
+            if (fclose(f) != 0 && r == SPX_OK && !to_device) {
+                set_error("write failed (disk full?)");
+                r = SPX_E_IO;
+            }
+            return r;
+        };
+        rc[t] = run();
+        if (rc[t] != SPX_OK) msg[t] = spx_last_error();  // the error text is thread-local: carry it over
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nt; ++t)
+        if (rc[t] != SPX_OK) {
+            set_error("%s", msg[t].c_str());
+            return rc[t];
+        }
+    return SPX_OK;
+}
+
 }  // namespace
 
 const char* spx_version(void) { return SPX_LAYOUT_VERSION; }
@@ -891,11 +962,13 @@ int spx_index_save(spx_index* ix, const char* path) {
         h.view = blank.view;
     }
     h.device_bytes = ix->device_bytes;
+    // the fat table and fat_j are not written: spx_index_load_flat rebuilds them from the other arrays (build_fat)
     uint64_t off = (sizeof h + 4095) & ~4095ull;
     for (int i = 0; i < spx_index::NARR; ++i) {
+        const bool skip = i == A_FAT || i == A_FATJ;
         h.arr_bytes[i] = ix->arr_bytes[i];
-        h.arr_offset[i] = off;
-        off = (off + ix->arr_bytes[i] + 4095) & ~4095ull;
+        h.arr_offset[i] = skip ? 0 : off;
+        if (!skip) off = (off + ix->arr_bytes[i] + 4095) & ~4095ull;
     }
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
@@ -903,26 +976,21 @@ int spx_index_save(spx_index* ix, const char* path) {
         set_error("cannot create %s", tmp.c_str());
         return SPX_E_IO;
     }
-    Staging sg;
-    int rc = sg.init();
-    if (rc == SPX_OK && fwrite(&h, sizeof h, 1, f) != 1) {
+    IoPool& pool = io_pool();
+    std::lock_guard<std::mutex> pg(pool.mu);
+    int rc = pool.init();
+    if (rc == SPX_OK && (fwrite(&h, sizeof h, 1, f) != 1 || ftruncate(fileno(f), (off_t)off) != 0)) {
         set_error("write failed");
         rc = SPX_E_IO;
-    }
-    void** arr[spx_index::NARR];
-    index_arrays(ix, arr);
-    for (int i = 0; i < spx_index::NARR && rc == SPX_OK; ++i) {
-        if (fseeko(f, (off_t)h.arr_offset[i], SEEK_SET) != 0) {
-            set_error("seek failed");
-            rc = SPX_E_IO;
-            break;
-        }
-        rc = write_from_device(f, *arr[i], h.arr_bytes[i], sg.stage, sg.st, sg.ev);
     }
     if (fclose(f) != 0 && rc == SPX_OK) {
         set_error("write failed (disk full?)");
         rc = SPX_E_IO;
     }
+    void** arr[spx_index::NARR];
+    index_arrays(ix, arr);
+    for (int i = 0; i < spx_index::NARR && rc == SPX_OK; ++i)
+        if (h.arr_offset[i]) rc = transfer_array(pool, tmp, h.arr_offset[i], *arr[i], h.arr_bytes[i], false, ix->device);
     if (rc == SPX_OK && rename(tmp.c_str(), path) != 0) {
         set_error("cannot rename %s to %s", tmp.c_str(), path);
         rc = SPX_E_IO;
@@ -964,21 +1032,29 @@ spx_index* spx_index_load_flat(const char* path, int device) {
     ix->n_text = h.n_text;
     ix->view = h.view;
     ix->device_bytes = h.device_bytes;
+    const bool timing = getenv("SPX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto body = [&]() -> int {
-        Staging sg;
-        int rc = sg.init();
+        double t0 = now();
+        IoPool& pool = io_pool();
+        std::lock_guard<std::mutex> pg(pool.mu);
+        int rc = pool.init();
         if (rc != SPX_OK) return rc;
+        if (timing) fprintf(stderr, "[spx] load_flat: staging pool %.3f s\n", now() - t0);
         void** arr[spx_index::NARR];
         index_arrays(ix, arr);
         for (int i = 0; i < spx_index::NARR; ++i) {
             ix->arr_bytes[i] = h.arr_bytes[i];
-            if (h.arr_bytes[i] == 0) continue;
+            if (h.arr_bytes[i] == 0 || h.arr_offset[i] == 0) continue;  // absent, or rebuilt below
             SPX_HIP(hipMalloc(arr[i], h.arr_bytes[i]));
-            if ((rc = read_to_device(f, h.arr_offset[i], *arr[i], h.arr_bytes[i], sg.stage, sg.st, sg.ev)) != SPX_OK)
-                return rc;
+            t0 = now();
+            if ((rc = transfer_array(pool, path, h.arr_offset[i], *arr[i], h.arr_bytes[i], true, device)) != SPX_OK) return rc;
+            if (timing) fprintf(stderr, "[spx] load_flat: array %d, %.2f GB in %.3f s\n", i, h.arr_bytes[i] / 1e9, now() - t0);
         }
-        SPX_HIP(hipStreamSynchronize(sg.st));
         bind_view(ix);
+        t0 = now();
+        if ((rc = build_fat(ix)) != SPX_OK) return rc;
+        if (timing) fprintf(stderr, "[spx] load_flat: fat table rebuilt in %.3f s\n", now() - t0);
         return init_runtime(ix);
     };
     const int rc = body();

@@ -9,7 +9,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -211,19 +213,20 @@ __global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* 
 }
 
 // block count table of letter c: cnt[fbase_c + b] = directory position of the first c-run whose
-// block (fat_block(run, bmul_c)) is >= b; qend_c when there is none
-__global__ void k_fill_cnt(const uint32_t* Qall, const uint8_t* Hs, const LetterInfo* letters,
-                           uint64_t r, uint32_t* cnt) {
-    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
-    if (i >= r) return;
-    LetterInfo li = letters[Hs[i]];
+// block (fat_block(run, bmul_c)) is >= b; qend_c when there is none.  blockIdx.y walks the letters that
+// occur, blockIdx.x strides over the letter's directory positions.
+__global__ void k_fill_cnt(const uint32_t* Qall, const LetterInfo* letters, const uint8_t* lets, uint64_t r,
+                           uint32_t* cnt) {
+    const LetterInfo li = letters[lets[blockIdx.y]];
     uint32_t* row = cnt + li.fbase;
     const int64_t nblk = (int64_t)fat_block((uint32_t)r, li.bmul) + 2;
-    int64_t b = fat_block(Qall[i], li.bmul);
-    int64_t pb = i > li.qbeg ? (int64_t)fat_block(Qall[i - 1], li.bmul) : -1;
-    for (int64_t x = pb + 1; x <= b; ++x) row[x] = (uint32_t)i;
-    if (i + 1 == li.qend)
-        for (int64_t x = b + 1; x < nblk; ++x) row[x] = li.qend;
+    for (uint64_t i = li.qbeg + blockIdx.x * (uint64_t)TPB + threadIdx.x; i < li.qend; i += (uint64_t)gridDim.x * TPB) {
+        int64_t b = fat_block(Qall[i], li.bmul);
+        int64_t pb = i > li.qbeg ? (int64_t)fat_block(Qall[i - 1], li.bmul) : -1;
+        for (int64_t x = pb + 1; x <= b; ++x) row[x] = (uint32_t)i;
+        if (i + 1 == li.qend)
+            for (int64_t x = b + 1; x < nblk; ++x) row[x] = li.qend;
+    }
 }
 
 // fat slot = digest of the jump row of the first c-run at or after the slot's block;
@@ -279,6 +282,65 @@ __global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, const uint32
 }
 
 }  // namespace
+
+// The fat table and fat_j from what the index already holds on the device: letters (geometry), Q, dirrows, aux.
+// Run by the flatten step and by spx_index_load_flat: the cache file does not carry the table (it is most of the
+// index -- 150 of 204 GB at 10^9 runs -- and takes a fraction of a second to rebuild, seconds to read).
+int build_fat(spx_index* ix) {
+    hipStream_t st = nullptr;
+    const uint64_t r = ix->view.r, nfat = ix->view.nfat;
+    const uint32_t fat_stride = ix->view.fat_stride;
+    std::vector<LetterInfo> hl(256);
+    SPX_HIP(hipMemcpy(hl.data(), ix->letters, 256 * sizeof(LetterInfo), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> lets;
+    uint64_t most_slots = 0, most_runs = 0;
+    for (int c = 0; c < 256; ++c)
+        if (hl[c].qend > hl[c].qbeg) {
+            lets.push_back((uint8_t)c);
+            most_slots = std::max<uint64_t>(most_slots, (uint64_t)fat_block((uint32_t)r, hl[c].bmul) + 2);
+            most_runs = std::max<uint64_t>(most_runs, hl[c].qend - hl[c].qbeg);
+        }
+    if (lets.empty()) {
+        set_error("index without letters");
+        return SPX_E_FORMAT;
+    }
+    DevBuf dl;
+    SPX_HIP(dl.alloc(256));
+    SPX_HIP(hipMemcpyAsync(dl.p, lets.data(), lets.size(), hipMemcpyHostToDevice, st));
+    if (ix->fat_j) (void)hipFree(ix->fat_j);
+    if (ix->fat) (void)hipFree(ix->fat);
+    ix->fat_j = nullptr;
+    ix->fat = nullptr;
+    const bool timing = getenv("SPX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    SPX_ALLOC0(ix->fat_j, nfat * 4 + 64);
+    SPX_ALLOC0(ix->fat, (nfat + 2) * (uint64_t)fat_stride);
+    if (timing) {
+        SPX_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[spx] build_fat: allocate + zero %.1f GB: %.3f s\n", (nfat * (fat_stride + 4.0)) / 1e9, now() - t0);
+        t0 = now();
+    }
+    const uint32_t* Qall = ix->q_alloc + 1;
+    const unsigned gc = most_runs / TPB + 1 < (1u << 20) ? (unsigned)(most_runs / TPB + 1) : (1u << 20);
+    k_fill_cnt<<<dim3(gc, (unsigned)lets.size()), TPB, 0, st>>>(Qall, ix->letters, dl.as<uint8_t>(), r, ix->fat_j);
+    if (timing) {
+        SPX_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[spx] build_fat: k_fill_cnt %.3f s\n", now() - t0);
+        t0 = now();
+    }
+    const unsigned gx = most_slots / TPB + 1 < (1u << 20) ? (unsigned)(most_slots / TPB + 1) : (1u << 20);
+    k_fill_fat<<<dim3(gx, (unsigned)lets.size()), TPB, 0, st>>>(ix->fat_j, ix->dirrows, ix->aux, Qall, ix->letters,
+                                                                 dl.as<uint8_t>(), r, ix->fat, fat_stride,
+                                                                 getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
+    SPX_HIP(hipGetLastError());
+    SPX_HIP(hipStreamSynchronize(st));
+    if (timing) fprintf(stderr, "[spx] build_fat: k_fill_fat %.3f s\n", now() - t0);
+    ix->arr_bytes[A_FAT] = (nfat + 2) * (uint64_t)fat_stride;
+    ix->arr_bytes[A_FATJ] = nfat * 4 + 64;
+    bind_view(ix);
+    return SPX_OK;
+}
 
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
@@ -485,11 +547,6 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     }
     const uint64_t nfat = (uint64_t)geometry(K, true);
     SPX_HIP(hipMemcpyAsync(ix->letters, hl.data(), 256 * sizeof(LetterInfo), hipMemcpyHostToDevice, st));
-    DevBuf cnt;
-    SPX_HIP(cnt.alloc(nfat * 4 + 64));
-    SPX_HIP(hipMemsetAsync(cnt.p, 0, nfat * 4 + 64, st));
-    k_fill_cnt<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), ix->letters, r, cnt.as<uint32_t>());
-    SPX_ALLOC0(ix->fat, (nfat + 2) * (uint64_t)fat_stride);
     SPX_ALLOC0(ix->q_alloc, (r + 1 + Q_PAD) * 4);
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
@@ -513,21 +570,15 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                                     docs ? dirdocs_tmp.as<uint32_t>() : nullptr, r + 1, ix->aux);
         bytes += (r + 2) * sizeof(Aux);
     }
+    // the fat table: built from the arrays above (also what spx_index_load_flat does instead of reading it)
+    ix->view.nletters = nletters;
+    ix->view.nfat = nfat;
+    ix->view.fat_stride = fat_stride;
+    ix->view.r = (uint32_t)r;
     {
-        DevBuf dl;
-        SPX_HIP(dl.alloc(256));
-        SPX_HIP(hipMemcpyAsync(dl.p, lets.data(), lets.size(), hipMemcpyHostToDevice, st));
-        uint64_t most = 0;  // slots of the letter with the most
-        for (uint8_t c : lets) most = std::max<uint64_t>(most, (uint64_t)fat_block((uint32_t)r, hl[c].bmul) + 2);
-        const unsigned gx = most / TPB + 1 < (1u << 20) ? (unsigned)(most / TPB + 1) : (1u << 20);
-        k_fill_fat<<<dim3(gx, nletters), TPB, 0, st>>>(cnt.as<uint32_t>(), ix->dirrows, ix->aux, Qall.as<uint32_t>(),
-                                                       ix->letters, dl.as<uint8_t>(), r, ix->fat, fat_stride,
-                                                       getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
-        SPX_HIP(hipGetLastError());
-        SPX_HIP(hipStreamSynchronize(st));
+        const int rc_fat = build_fat(ix);
+        if (rc_fat != SPX_OK) return rc_fat;
     }
-    ix->fat_j = (uint32_t*)cnt.p;  // the block count table stays: it is fat_j
-    cnt.p = nullptr;
     bytes += nfat * 4 + 64;
     if (docs) {
         SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));

@@ -208,6 +208,8 @@ inline int chunk_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
     *out = sc.p;
     return SPX_OK;
 }
+// spx_flatten.hip: (re)builds fat / fat_j from letters, Q, dirrows and aux (view.r / nfat / fat_stride set)
+int build_fat(spx_index* ix);
 // spx_walk.hip: MS text against the index: text[samples_start[k]] must be the head of run k
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream);
 // spx_flatten.hip: builds every device array of `ix` from raw per-run arrays
