@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace spumoni_host {
 
@@ -19,13 +20,21 @@ bool read_whole_file(const std::string& path, std::vector<uint8_t>& out) {
 }
 
 static void unpack5(const std::vector<uint8_t>& raw, size_t stride, size_t pick, std::vector<uint64_t>& out) {
+    // 10^9 records take seconds on one thread (and so does first touching 8 GB of output): eight threads
     const size_t n = raw.size() / (5 * stride);
     out.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint64_t v = 0;
-        std::memcpy(&v, raw.data() + (i * stride + pick) * 5, 5);
-        out[i] = v;
-    }
+    const unsigned nt = n >= (1u << 22) ? 8 : 1;
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) {
+            uint64_t v = 0;
+            std::memcpy(&v, raw.data() + (i * stride + pick) * 5, 5);
+            out[i] = v;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
 }
 
 bool load_raw_index(const std::string& prefix, bool want_samples, RawIndex& out, std::string& err) {
