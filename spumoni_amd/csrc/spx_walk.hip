@@ -659,11 +659,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     fb |= (uint64_t)rflag << (slot * 8);
                     if (slot == 0 || xi == 0) {
                         const uint64_t g8 = gi & ~7ull;
-#ifdef SPX_EXP_NOFLAGS
-                        if (false) {
-#else
                         if (g8 >= base && g8 + 7 < base + m) {
-#endif
                             *reinterpret_cast<uint64_t*>(b.ch.flags + g8) = fb;
                         } else {
 #pragma unroll
@@ -690,11 +686,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     else
                         b.out_docs[gi] = doc;
                 }
-#ifdef SPX_EXP_NOEMIT
-            } else if (false) {
-#else
             } else if (MODE == SPX_MODE_PML) {
-#endif
                 // lengths[m-i-1] = length   (:281)
                 // (out_lengths == NULL: classification only -- the walk then runs at the gather ceiling)
                 if (b.out_lengths == nullptr) {
@@ -702,11 +694,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     stage_n<LEN_G, NARROW>(obn, length, b.out_lengths, base, xi, m);
                 else
                     b.out_lengths[gi] = length;
-#ifdef SPX_EXP_NOEMIT
-            } else if (MODE == SPX_MODE_MS) {
-#else
             } else {
-#endif
                 // ms_pointers[m-i-1] = sample   (:618), staged PTR_G at a time: elements [xi & ~(PTR_G-1), ...] of the read
                 const uint32_t slot = xi & (PTR_G - 1);
 #pragma unroll
@@ -729,11 +717,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 else
                     b.out_docs[gi] = doc;
             }
-#if defined(SPX_EXP_NOEMIT) || defined(SPX_EXP_NOCLASS)
-            if (false) {
-#else
             if (want_class) {
-#endif
                 if (xi < bin_lo) {  // crossed into the previous bin (descending index)
                     if (bin_max >= b.max_value_thr)
                         above++;
@@ -804,11 +788,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             peek = false;
             if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
                 // checkpoint: the state before character base + x - 1
-#ifdef SPX_EXP_NOCKPT
-                if (false) {
-#else
                 if (CHUNK == 1) {
-#endif
                     b.ch.ckpt[(base + x) >> CKPT_SHIFT] =
                         WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                 } else {

@@ -4,9 +4,13 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spumoni_amd import capi, synth
 
-raw = synth.statistical_rlbwt(1 << 26, 253, 8.0, seed=3, device="cuda", zipf=1.0)
-seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13)
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # random warm-up characters of the positive reads (bench.py: 4)
+raw = synth.statistical_rlbwt(runs, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+seqs, offs = synth.simulate_reads(raw, 10_000_000, 44, seed=13, warmup=warm)
+print(f"index r = {runs}, reads with {warm} warm-up characters")
 ix = capi.Index.from_raw(raw, 0)
+del raw; torch.cuda.empty_cache()
 hs, ho = seqs.cpu().numpy(), offs.cpu().numpy()
 for rep in range(3):
     t0 = time.time()
