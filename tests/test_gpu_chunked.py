@@ -135,3 +135,36 @@ def test_automatic_choice_and_device_entry_point(oracle_mod):
         c32 = d_cls.view(torch.int32).view(nreads, 4).cpu().numpy()
         assert np.array_equal(c32[:, 2].view(np.uint32), a) and np.array_equal(c32[:, 3].view(np.uint32), b)
         assert np.array_equal(d_cls[:, 0].cpu().numpy().view(np.uint64), s)
+
+
+def test_pipelined_host_batch_pieces_take_the_chunked_walk(oracle_mod):
+    """A host batch of >= 2^18 reads and >= 64 MB runs as a pipeline of eight pieces whose offsets stay absolute: every
+    piece takes the chunked walk with its scratch (flags, checkpoints) indexed from the piece's first character.  Same
+    values as the plain walk of the whole batch, and as the oracle on a sample."""
+    raw = synth.statistical_rlbwt(1 << 18, 60, 6.0, seed=8, device="cuda", zipf=1.0, with_samples=True, n_docs=7)
+    nreads = 8 * 32768 + 5
+    rng = np.random.default_rng(2)
+    lens = rng.integers(400, 700, size=nreads)
+    lens[::1000] = 0  # some empty reads
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pool, _ = synth.simulate_reads(raw, 4096, 700, seed=9, f_mis=0.05, warmup=3)
+    pool = pool.cpu().numpy().reshape(4096, 700)
+    seqs = np.concatenate([pool[q % 4096, 700 - l:] for q, l in enumerate(lens)])
+    assert seqs.size >= (64 << 20)
+    ix = capi.Index.from_raw(raw, 0)
+    ix.set_option("chunk_mode", 1)
+    want = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, classify=(150, 5))
+    want_ms = ix.query_host(capi.SPX_MODE_MS, seqs, offs, want_lengths=False, want_docs=True)
+    ix.set_option("chunk_mode", 2)
+    ix.set_option("chunk_len", 96)
+    for bits in (32, 16):
+        got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, classify=(150, 5), bits=bits)
+        assert ix.last_chunk_stats()["chunk_len"] == 96
+        assert np.array_equal(got["lengths"], want["lengths"]) and np.array_equal(got["docs"], want["docs"])
+        assert np.array_equal(got["class"], want["class"])
+    got_ms = ix.query_host(capi.SPX_MODE_MS, seqs, offs, want_lengths=False, want_docs=True)
+    assert np.array_equal(got_ms["pointers"], want_ms["pointers"]) and np.array_equal(got_ms["docs"], want_ms["docs"])
+    ns = 300
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    wl, wd = orc.pml(seqs[: offs[ns]], offs[: ns + 1], want_docs=True)
+    assert np.array_equal(want["lengths"][: offs[ns]], wl) and np.array_equal(want["docs"][: offs[ns]], wd)
