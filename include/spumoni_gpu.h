@@ -112,6 +112,16 @@ int spx_index_device_bytes(const spx_index *ix, uint64_t *bytes);
  * the check (synthetic indexes that are not the BWT of any text).              */
 #define SPX_TEXT_UNCHECKED 2
 int spx_index_set_text(spx_index *ix, const uint8_t *text, uint64_t n_text, int where);
+/* The same text from the MS index itself, when no copy of it is at hand (the reference's own
+ * index files hold everything needed: run heads, run lengths, samples_start): the BWT character
+ * at position p is text[SA[p] - 1], samples_start[k] names that text position for the first
+ * position of run k, and every LF step moves one position to the left -- one lane per run walks
+ * LF until it reaches the first position of a run.  n steps in all, a fraction of a second per
+ * 10^9 characters.  Needs an index built with SA samples.                                   */
+int spx_index_rebuild_text(spx_index *ix);
+/* The text the index holds (set or rebuilt), e.g. to keep it as a file next to the index.  out NULL:
+ * only *n_text is filled.  where: 0 host, 1 device.                                              */
+int spx_index_copy_text(spx_index *ix, uint8_t *out, uint64_t capacity, int where, uint64_t *n_text);
 
 /* ---- flat-layout cache and replication -------------------------------------
  * pml_t / ms_t deserialise their index on every run (compute_ms_pml.cpp:700-721,

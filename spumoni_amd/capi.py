@@ -48,6 +48,8 @@ EXPORTS = [
     "spx_index_clone",
     "spx_index_describe",
     "spx_last_chunk_stats",
+    "spx_index_rebuild_text",
+    "spx_index_copy_text",
 ]
 SPX_TEXT_UNCHECKED = 2
 
@@ -131,6 +133,8 @@ def lib() -> C.CDLL:
         L.spx_index_clone.argtypes = [vp, i32]
         L.spx_index_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.spx_last_chunk_stats.argtypes = [vp, C.POINTER(u64 * 4)]
+        L.spx_index_rebuild_text.argtypes = [vp]
+        L.spx_index_copy_text.argtypes = [vp, vp, u64, i32, C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -228,6 +232,18 @@ class Index:
         buf = C.create_string_buffer(1024)
         _check(lib().spx_index_describe(self._h, buf, 1024))
         return json.loads(buf.value.decode())
+
+    def rebuild_text(self) -> None:
+        """The indexed text from the MS index itself (LF chains from the SA samples): no text file needed."""
+        _check(lib().spx_index_rebuild_text(self._h))
+
+    def text(self) -> np.ndarray:
+        """The text the index holds (set or rebuilt), as a host array."""
+        n = C.c_uint64()
+        _check(lib().spx_index_copy_text(self._h, None, 0, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().spx_index_copy_text(self._h, _np_ptr(out), n.value, 0, C.byref(n)))
+        return out
 
     def set_text(self, text, unchecked: bool = False) -> None:
         """unchecked: skip the text-against-index validation (synthetic indexes that are no text's BWT)."""

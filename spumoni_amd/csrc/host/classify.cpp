@@ -67,11 +67,8 @@ void IndexSet::load(const RunOptions& o) {
         }
         if (o.use_doc && !load_doc_array(o.ref_file + ".doc", raw, err)) fatal_error("%s", err.c_str());
         std::vector<uint8_t> text;
-        if (o.ms) {
-            if (o.text_file.empty() || !read_whole_file(o.text_file, text))
-                fatal_error("MS lengths need the indexed text as a plain file (set SPUMONI_TEXT): the SLP of the\n"
-                            "       reference is replaced by plain text in GPU memory (see DESIGN.md)");
-        }
+        if (o.ms && !o.text_file.empty() && !read_whole_file(o.text_file, text))
+            fatal_error("cannot read the text file %s (SPUMONI_TEXT)", o.text_file.c_str());
         first = spx_index_from_runs(raw.heads.data(), raw.lens.data(), raw.thr.data(), raw.heads.size(),
                                     o.ms ? raw.ssa.data() : nullptr, o.ms ? raw.esa.data() : nullptr,
                                     o.use_doc ? raw.doc_start.data() : nullptr,
@@ -79,8 +76,14 @@ void IndexSet::load(const RunOptions& o) {
         if (!first) fatal_error("%s", spx_last_error());
         // the text is checked against the index (length, and text[samples_start[k]] == head of run k):
         // a text that is not the indexed one is refused instead of giving wrong .lengths
-        if (o.ms && spx_index_set_text(first, text.data(), text.size(), 0) != SPX_OK)
-            fatal_error("%s (SPUMONI_TEXT must be the exact text the index was built from)", spx_last_error());
+        // ms_t reads the text through the SLP (<ref>.slp, :769-774); here it is plain text in GPU memory: from
+        // SPUMONI_TEXT when given (checked against the index), otherwise rebuilt from the index itself
+        if (o.ms && !o.text_file.empty()) {
+            if (spx_index_set_text(first, text.data(), text.size(), 0) != SPX_OK)
+                fatal_error("%s (SPUMONI_TEXT must be the exact text the index was built from)", spx_last_error());
+        } else if (o.ms) {
+            if (spx_index_rebuild_text(first) != SPX_OK) fatal_error("%s", spx_last_error());
+        }
         if (policy == "write" && spx_index_save(first, cache.c_str()) != SPX_OK)
             std::fprintf(stderr, "\n[spumoni-gpu] could not write %s: %s\n", cache.c_str(), spx_last_error());
     }

@@ -5,7 +5,8 @@
 //
 // Differences that are ours, all additive:
 //   SPUMONI_GPUS=0,1,..   devices to use (default 0); reads are sharded, index replicated
-//   SPUMONI_TEXT=<file>   plain indexed text for the MS length extension (replaces <ref>.slp)
+//   SPUMONI_TEXT=<file>   plain indexed text for the MS length extension (optional: without it the text
+//                         <ref>.slp encodes is rebuilt from the MS index itself)
 //   the index is read from the raw run files kept by `spumoni build -k`
 //   (<ref>.bwt.heads/.bwt.len/.thr_pos[/.ssa/.esa]); -t is accepted and ignored
 //   (output is always in input order, the reference's -t 1 order).

@@ -323,6 +323,75 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
     return SPX_OK;
 }
 
+int spx_index_rebuild_text(spx_index* ix) {
+    if (!ix) {
+        set_error("index is null");
+        return SPX_E_ARG;
+    }
+    if (!ix->has_samples) {
+        set_error("the text can only be rebuilt from an index with SA samples (an MS index)");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    const uint64_t n_text = ix->n - 1;
+    if (ix->text) (void)hipFree(ix->text);
+    ix->text = nullptr;
+    ix->n_text = 0;
+    ix->arr_bytes[A_TEXT] = 0;
+    bind_view(ix);
+    uint8_t* d_text = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    SPX_HIP(hipMalloc((void**)&d_text, n_text + 16));
+    SPX_HIP(hipMemset(d_text, 0, n_text + 16));
+    SPX_HIP(hipMalloc((void**)&d_cnt, 16));
+    SPX_HIP(hipMemset(d_cnt, 0, 16));
+    int rc = launch_text_from_index(ix, d_text, n_text, d_cnt, nullptr);
+    unsigned long long stuck = 0;
+    if (rc == SPX_OK && hipMemcpy(&stuck, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SPX_E_HIP;
+    if (rc == SPX_OK && stuck) {
+        set_error("the run structure is not a permutation (%llu LF chains did not end): corrupt index", stuck);
+        rc = SPX_E_FORMAT;
+    }
+    if (rc == SPX_OK) {
+        ix->text = d_text;
+        ix->n_text = n_text;
+        ix->arr_bytes[A_TEXT] = n_text + 16;
+        bind_view(ix);
+        // (the chains partition the BWT positions of a consistent run structure; the check below confirms the
+        // samples' positions, which is what spx_index_set_text checks of a text handed in)
+        SPX_HIP(hipMemset(d_cnt, 0, 8));
+        rc = launch_text_check(ix, d_cnt, nullptr);
+        unsigned long long bad = 0;
+        if (rc == SPX_OK && hipMemcpy(&bad, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SPX_E_HIP;
+        if (rc == SPX_OK && bad) {
+            set_error("the rebuilt text disagrees with the index at %llu runs: SA samples and run structure do not belong together", bad);
+            rc = SPX_E_FORMAT;
+        }
+    } else {
+        (void)hipFree(d_text);
+    }
+    (void)hipFree(d_cnt);
+    return rc;
+}
+
+int spx_index_copy_text(spx_index* ix, uint8_t* out, uint64_t capacity, int where, uint64_t* n_text) {
+    if (!ix) {
+        set_error("index is null");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (n_text) *n_text = ix->n_text;
+    if (!out) return SPX_OK;  // size query
+    if (!ix->text || capacity < ix->n_text) {
+        set_error(ix->text ? "buffer too small for the text" : "the index has no text");
+        return SPX_E_ARG;
+    }
+    SPX_HIP(hipSetDevice(ix->device));
+    SPX_HIP(hipMemcpy(out, ix->text, ix->n_text, where ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return SPX_OK;
+}
+
 void* spx_host_alloc(size_t bytes) {
     if (usable_devices() <= 0) {
         set_error("no HIP device visible: libspumoni_gpu has no CPU fallback");

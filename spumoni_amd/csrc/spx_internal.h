@@ -212,6 +212,8 @@ inline int chunk_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
 int build_fat(spx_index* ix);
 // spx_walk.hip: MS text against the index: text[samples_start[k]] must be the head of run k
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream);
+// spx_walk.hip: the indexed text from the MS index (LF chains from every run's first position)
+int launch_text_from_index(spx_index* ix, uint8_t* d_text, uint64_t n_text, unsigned long long* d_stuck, hipStream_t stream);
 // spx_flatten.hip: builds every device array of `ix` from raw per-run arrays
 // that already live on the device.
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,

@@ -980,6 +980,44 @@ __global__ void k_text_check(const DevIndex ix, unsigned long long* bad) {
 
 // items: reads (CHUNK == 0) or an upper bound of the chunks (the kernel reads the real count from
 // device memory)
+// The indexed text from the MS index itself ("by parallel BWT inversion from SA samples"): ms_t reads
+// the text through an SLP (compute_ms_pml.cpp:769-774, 805); here it is plain text in HBM, and when no text file
+// is at hand it is rebuilt from the index.  The BWT character at position p is text[SA[p] - 1]; samples_start[k]
+// is that text position for the first position of run k, and every LF step moves one text position to the left.
+// One lane per run walks LF from the run's first position, writing the head of the run it is in, until it lands
+// on the first position of a run (whose own lane goes on from there).  The chains partition the BWT: n steps in
+// all, n / r per lane on average.
+__global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_text, unsigned long long* stuck) {
+    const uint64_t k_start = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    if (k_start >= ix.r) return;
+    uint64_t t = ix.ss_by_run[k_start];
+    uint32_t k = (uint32_t)k_start;
+    uint64_t off = 0;
+    for (uint64_t guard = 0;; ++guard) {
+        const Row row = ix.rows[k];
+        const uint32_t H = ix.compact ? crow_H(row) : row_H(row);
+        if (t < n_text) text[t] = (uint8_t)H;
+        // LF of (k, off): run LFrun at offset LFoff + off, or a later run when that overshoots
+        uint32_t k0 = ix.compact ? crow_LFrun(row) : row_LFrun(row);
+        uint64_t offp = (ix.compact ? (uint64_t)crow_LFoff(row) : row_LFoff(row)) + off;
+        for (;;) {
+            const Row r0 = ix.rows[k0];
+            const uint64_t len = ix.compact ? (uint64_t)crow_len(r0) : row_len(r0);
+            if (offp < len || k0 >= ix.r) break;
+            offp -= len;
+            k0++;
+        }
+        if (offp == 0 || k0 >= ix.r) break;  // the first position of a run: its own lane takes over
+        if (guard > ix.n) {                  // not a permutation: corrupt run structure
+            atomicAdd(stuck, 1ull);
+            break;
+        }
+        k = k0;
+        off = offp;
+        t -= 1;
+    }
+}
+
 template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
 int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint64_t items = 0) {
     if (CHUNK == 0) items = args.nreads;
@@ -1411,6 +1449,13 @@ int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_c
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream) {
     const unsigned grid = (unsigned)((ix->r + WALK_TPB - 1) / WALK_TPB);
     k_text_check<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, d_bad);
+    SPX_HIP(hipGetLastError());
+    return SPX_OK;
+}
+
+int launch_text_from_index(spx_index* ix, uint8_t* d_text, uint64_t n_text, unsigned long long* d_stuck, hipStream_t stream) {
+    const unsigned grid = (unsigned)((ix->r + WALK_TPB - 1) / WALK_TPB);
+    k_text_from_index<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, d_text, n_text, d_stuck);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }

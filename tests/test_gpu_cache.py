@@ -95,3 +95,23 @@ def test_text_that_is_not_the_indexed_text_is_refused():
     ix.set_text(t)
     got = ix.query_host(capi.SPX_MODE_MS, text[100:180], np.array([0, 80]))
     assert got["lengths"][0] >= 80 - 0  # a substring of the text matches to its end
+
+
+@pytest.mark.parametrize("seed,letters,wide", [(41, DNA, 0), (42, [3, 4, 5, 90, 127, 128, 129, 200, 255], 0), (43, DNA + [ord("N")], 1)])
+def test_text_rebuilt_from_the_index_is_the_text(oracle_mod, seed, letters, wide, monkeypatch):
+    """ms_t needs the indexed text (through an SLP upstream); spx_index_rebuild_text recovers it from the MS index
+    itself -- LF chains from every run's SA sample.  It must be the text byte for byte, and MS lengths computed with
+    it must be the oracle's."""
+    if wide:
+        monkeypatch.setenv("SPX_ROWS_WIDE", "1")
+    raw, text = cases.real_case(seed, 7000, letters, ndocs=3)
+    raw.text = None
+    ix = capi.Index.from_raw(raw, 0)
+    ix.rebuild_text()
+    assert np.array_equal(ix.text(), text)
+    rng = np.random.default_rng(seed)
+    seqs, offs = cases.reads_mixed(rng, text, letters, 200, 150, [2])
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
+    pml_only = capi.Index.from_raw(synth.RawIndex(heads=raw.heads, lens=raw.lens, thr=raw.thr, n=raw.n), 0)
+    with pytest.raises(capi.SpxError, match="SA samples"):
+        pml_only.rebuild_text()

@@ -53,14 +53,17 @@ def _setup(tmp_path, seed, letters, n=6000, nreads=300):
     return ref, prefix, seqs, offs, rng
 
 
-def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, fastq=False, digest="n", kw=()):
+def _run_both(tmp_path, ref, prefix, reads_name, seqs, offs, rng, flags, mode, fastq=False, digest="n", kw=(), give_text=True):
     a_dir, b_dir = tmp_path / "gpu", tmp_path / "orc"
     for d in (a_dir, b_dir):
         shutil.rmtree(d, ignore_errors=True)
         d.mkdir()
     _write_fasta(a_dir / reads_name, seqs, offs, np.random.default_rng(77), fastq)
     shutil.copy(a_dir / reads_name, b_dir / reads_name)
-    env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext")
+    env = dict(os.environ)
+    env.pop("SPUMONI_TEXT", None)
+    if give_text:  # otherwise `run -M` rebuilds the text from the MS index itself
+        env["SPUMONI_TEXT"] = prefix + ".rawtext"
     cmd = [HOST_BIN, "run", "-r", ref, "-p", str(a_dir / reads_name), "-" + digest, mode] + flags
     orc_kw = []
     if kw:
@@ -332,3 +335,10 @@ def test_end_to_end_minimizer_index_from_fasta(built, tmp_path):
     rep = open(tmp_path / "gpu" / "reads.fa.report").read().splitlines()[1:]
     found = sum("FOUND" in ln and "NOT_PRESENT" not in ln for ln in rep)
     assert 0.3 * len(rep) < found < 0.7 * len(rep)
+
+
+def test_cli_ms_without_a_text_file(built, tmp_path):
+    """`run -M` could not work from the index files alone (the reference reads the text through <ref>.slp).
+    Without SPUMONI_TEXT the text is rebuilt from the MS index: .lengths / .pointers / .doc_numbers / .report identical."""
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 47, list(b"ACGT"))
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d"], "-M", give_text=False)

@@ -13,6 +13,9 @@ torch.cuda.synchronize(); print(f"index build {time.time()-t0:.1f}s  n={raw.n} r
 nreads, m = 1_000_000, 250
 seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
 ix = capi.Index.from_raw(raw, 0)
+t0 = time.time(); ix.rebuild_text(); dt = time.time() - t0
+print(f"text rebuilt from the MS index (LF chains from the SA samples): {dt*1e3:.1f} ms for n = {raw.n}, identical to the text: "
+      f"{bool(np.array_equal(ix.text(), text))}")
 d_seqs = capi.pad_seqs(torch.from_numpy(seqs).cuda()); d_offs = torch.from_numpy(offs).cuda()
 tot = nreads * m
 d_len = torch.empty(tot, dtype=torch.int32, device="cuda"); d_ptr = torch.empty(tot, dtype=torch.int64, device="cuda")
