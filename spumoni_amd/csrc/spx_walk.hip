@@ -822,35 +822,46 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
 // One lane per read; `l` is carried exactly like the reference; characters are
 // compared eight at a time (two aligned 64-bit loads + funnel shift per side).
 // ---------------------------------------------------------------------------
-// ascending counterpart of stage8 (the extension walks a read left to right): elements [i & ~7, i | 7] of
-// the read, written when the group's highest element -- or the read's last -- has been produced
-__device__ __forceinline__ void stage8_up(uint64_t& lo, uint64_t& hi, uint32_t value, uint32_t* out, uint64_t base,
-                                          uint32_t i, bool last) {
-    const uint32_t slot = i & 7;
-    const uint64_t v = (uint64_t)(value & 0xffffu) << ((slot & 3) * 16);
-    lo |= (slot & 4) ? 0ull : v;
-    hi |= (slot & 4) ? v : 0ull;
-    if (slot == 7 || last) {
-        uint32_t* o = out + base + (i - slot);
-        const uint32_t cnt = slot + 1;
-        if (cnt == 8) {
-            *reinterpret_cast<U32x4*>(o) = widen4(lo);
-            *reinterpret_cast<U32x4*>(o + 4) = widen4(hi);
-        } else {
-            uint64_t src = lo;
-            if (cnt & 4) {
-                *reinterpret_cast<U32x4*>(o) = widen4(lo);
-                src = hi;
-                o += 4;
+// ascending counterpart of stage_n (the extension walks a read left to right): elements [i & ~(G-1), ...] of the
+// read as u16 in G / 4 registers, written as 32-bit values when the group's highest element -- or the read's
+// last -- has been produced
+template <int G>
+__device__ __forceinline__ void stage_up(StageN<G>& st, uint32_t value, uint32_t* out, uint64_t base, uint32_t i,
+                                         bool last) {
+    const uint32_t idx = i & (G - 1), r = idx >> 2;
+    const uint64_t v = (uint64_t)(value & 0xffffu) << ((idx & 3) * 16);
+#pragma unroll
+    for (int j = 0; j < G / 4; ++j) st.a[j] |= (r == (uint32_t)j) ? v : 0ull;
+    if (idx == G - 1 || last) {
+        uint32_t* o = out + base + (i - idx);
+        const uint32_t cnt = idx + 1;
+#pragma unroll
+        for (int q = 0; q < G / 8; ++q) {
+            const uint64_t lo = st.a[2 * q], hi = st.a[2 * q + 1];
+            if (cnt > 8u * q) {
+                const uint32_t c = cnt - 8 * q;
+                uint32_t* p = o + 8 * q;
+                if (c >= 8) {
+                    *reinterpret_cast<U32x4*>(p) = widen4(lo);
+                    *reinterpret_cast<U32x4*>(p + 4) = widen4(hi);
+                } else {
+                    uint64_t src = lo;
+                    if (c & 4) {
+                        *reinterpret_cast<U32x4*>(p) = widen4(lo);
+                        src = hi;
+                        p += 4;
+                    }
+                    if (c & 2) {
+                        *reinterpret_cast<U32x2*>(p) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
+                        src >>= 32;
+                        p += 2;
+                    }
+                    if (c & 1) *p = (uint32_t)src & 0xffff;
+                }
             }
-            if (cnt & 2) {
-                *reinterpret_cast<U32x2*>(o) = U32x2{(uint32_t)src & 0xffff, (uint32_t)(src >> 16) & 0xffff};
-                src >>= 32;
-                o += 2;
-            }
-            if (cnt & 1) *o = (uint32_t)src & 0xffff;
         }
-        lo = hi = 0;
+#pragma unroll
+        for (int j = 0; j < G / 4; ++j) st.a[j] = 0;
     }
 }
 
@@ -885,7 +896,7 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
     const uint64_t n = ix.n_text;
     const bool want_class = b.out_class != nullptr;
     uint64_t l = 0, prev = 0;
-    uint64_t ob_lo = 0, ob_hi = 0;  // staged lengths (u16) of the aligned group of 8
+    StageN<LEN_G> obu{};  // staged lengths
     const bool staged = m < 65536;
     // classifier over ascending indices
     const uint64_t w = b.bin_width ? b.bin_width : 1;
@@ -933,7 +944,7 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
             if (b.narrow)
                 out16[gi] = (uint16_t)l;
             else if (staged)
-                stage8_up(ob_lo, ob_hi, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
+                stage_up<LEN_G>(obu, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
             else
                 b.out_lengths[gi] = (uint32_t)l;
             if (want_class) {
