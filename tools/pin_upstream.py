@@ -15,8 +15,9 @@ What an external run must supply -- one directory <dir> holding
       ref.fa.doc                                        document array          (only with -d)
       ref.fa.pmlnulldb  ref.fa.msnulldb                 null databases
       ref.fa.rawtext                                    OPTIONAL: the concatenated text PFP indexed,
-                                                        one byte per character, no terminator (for MS
-                                                        lengths; `.lengths` is skipped without it)
+                                                        one byte per character, no terminator (the CPU
+                                                        oracle harness needs it for MS; the HIP CLI
+                                                        rebuilds the text from the MS index without it)
   queries and upstream results, from `spumoni run -t 1 -r <dir>/ref -p <dir>/reads.fa <flags>`:
       reads.fa                                          the patterns
       expected/P/reads.fa.pseudo_lengths [.doc_numbers] [.report]        flags -P [-d] [-c]
@@ -112,7 +113,7 @@ def run_and_compare(tag, binary_kind, d, prefix, mode, digest_flag, kw, text):
     files = sorted(os.listdir(exp))
     use_doc = any(f.endswith(".doc_numbers") for f in files)
     rep = any(f.endswith(".report") for f in files)
-    if mode == "M" and text is None:
+    if mode == "M" and text is None and binary_kind == "oracle":
         files = [f for f in files if not f.endswith(".lengths") and not f.endswith(".report")]
     work = tempfile.mkdtemp(prefix="pin_")
     try:
