@@ -610,13 +610,16 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     a.max_value_thr = max_value_thr;
     a.counters = ix->counters;
     a.narrow = narrow ? 1 : 0;
+    if ((rc = prepare_len_mask(ix, mode, a)) != SPX_OK) return rc;
     SPX_HIP(hipEventRecord(ix->ev0, st));
+    bool chunked = false;
     if (nreads > 0) {
-        bool chunked = false;
         if ((rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
         if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st)) != SPX_OK) return rc;
     }
     SPX_HIP(hipEventRecord(ix->ev1, st));
+    // PML: the plain walk left one bit per character; the lengths are written from them here
+    if (nreads > 0 && !chunked && (rc = launch_len_expand(ix, a, st)) != SPX_OK) return rc;
     if (mode == SPX_MODE_MS && d_out_lengths && nreads > 0) {
         a.out_class = d_out_class;
         rc = launch_ms_extend(ix, a, st);
@@ -727,10 +730,13 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         args.max_value_thr = max_value_thr;
         args.counters = ix->counters;
         args.narrow = width == 2 ? 1 : 0;
+        if ((rc = prepare_len_mask(ix, mode, args)) != SPX_OK) return rc;
         {  // a chunk of few, long reads is cut further and walked chunk-wise (spx_walk.hip)
             bool chunked = false;
             if ((rc = launch_walk_chunked(ix, mode, args, b - a, s_k, &chunked, a)) != SPX_OK) return rc;
-            if (!chunked && (rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK) return rc;
+            if (!chunked && ((rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK ||
+                             (rc = launch_len_expand(ix, args, s_k)) != SPX_OK))
+                return rc;
         }
         if (mode == SPX_MODE_MS && dlen) {
             args.out_class = dcls ? (spx_class*)dcls + q0 : nullptr;

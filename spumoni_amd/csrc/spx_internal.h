@@ -113,6 +113,12 @@ struct BatchArgs {
     uint32_t narrow;          // out_lengths / out_docs point to uint16_t arrays (reads < 65536 characters)
     ChunkArgs ch;             // chunked walks only
     const uint32_t* only_flagged;  // plain walk: skip the reads whose flag is 0 (fallback after chunking)
+    // PML, plain walk: the lengths leave the walk as ONE BIT per character (length == 0, i.e. "reset here":
+    // a PML length is the distance to the next reset at or after it, compute_ms_pml.cpp:249-250, 266-276) and
+    // k_expand_lengths writes out_lengths from the bits as a stream.  Read q's bits: 16-byte pairs of words
+    // [((offs[q] - offs[0]) >> 7) + q, ...) (pairs of different reads never overlap), bit p & 63 of word p >> 6
+    // for character p of the read.
+    uint64_t* len_mask;
 };
 
 }  // namespace spx
@@ -157,7 +163,7 @@ struct spx_index {
     struct Scratch {
         void* p = nullptr;
         size_t cap = 0;
-    } scratch[8], chunk_scr[8];  // host-buffer queries; chunked walks (under mu)
+    } scratch[8], chunk_scr[9];  // host-buffer queries; chunked walks and the length bits (under mu)
     int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
     int chunk_shift = 0;  // "chunk_shift" option: log2 of the chunk size (0 = automatic)
     int chunk_len = 0;    // "chunk_len" option: chunk size in characters (rounded up to 16; 0 = automatic)
@@ -223,6 +229,10 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
                 hipStream_t stream);
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream);
+// PML lengths through one bit per character: prepare_len_mask before the walk (sets args.len_mask; nothing
+// to do for MS or a classification-only query), launch_len_expand after it
+int prepare_len_mask(spx_index* ix, int mode, BatchArgs& args);
+int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // long-read batches: the chunked walk (returns SPX_OK and sets *done = false when the batch does not
 // qualify and the plain walk should run)
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,

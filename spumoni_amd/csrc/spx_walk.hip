@@ -259,7 +259,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint64_t wbase = 0;
 #define WIN_CHAR(wi) ((s_win[((wi) >> 2) * WALK_TPB + threadIdx.x] >> (((wi)&3) * 8)) & 0xffu)
     // output staging (PML): u16 values of the current group of outputs
-    StageN<LEN_G> obn{};  // PML lengths
+    StageN<LEN_G> obn{};  // PML lengths (pass 1 of the chunked walk)
+    // PML lengths of the plain walk: one bit per character (BatchArgs::len_mask), one 16-byte store per 128
+    // characters -- for a read of up to 128 characters a single store when the read is done
+    uint64_t mbits = 0, mbits_hi = 0;
+    const uint64_t base0 = (CHUNK == 0 && MODE == SPX_MODE_PML && b.len_mask != nullptr) ? b.offs[0] : 0;
     StageN<DOC_G> dbn{};  // document ids
     uint64_t pbs[PTR_G] = {};  // MS pointers of the current group
     // classifier
@@ -689,7 +693,18 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             } else if (MODE == SPX_MODE_PML) {
                 // lengths[m-i-1] = length   (:281)
                 // (out_lengths == NULL: classification only -- the walk then runs at the gather ceiling)
-                if (b.out_lengths == nullptr) {
+                if (CHUNK == 0) {
+                    if (b.len_mask != nullptr) {
+                        const uint64_t bit = (uint64_t)(length == 0) << (xi & 63);
+                        mbits |= (xi & 64) ? 0 : bit;
+                        mbits_hi |= (xi & 64) ? bit : 0;
+                        if ((xi & 127) == 0) {
+                            *reinterpret_cast<P64x2*>(b.len_mask + 2 * (((base - base0) >> 7) + rd + (xi >> 7))) =
+                                P64x2{mbits, mbits_hi};
+                            mbits = 0;
+                            mbits_hi = 0;
+                        }
+                    }
                 } else if (NARROW || m < 65536)
                     stage_n<LEN_G, NARROW>(obn, length, b.out_lengths, base, xi, m);
                 else
@@ -1032,6 +1047,10 @@ __global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_t
 template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
 int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint64_t items = 0) {
     if (CHUNK == 0) items = args.nreads;
+    if (CHUNK == 0 && MODE == SPX_MODE_PML && args.out_lengths != nullptr && args.len_mask == nullptr) {
+        set_error("internal: PML walk without prepare_len_mask");
+        return SPX_E_ARG;
+    }
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
@@ -1309,7 +1328,8 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
     }
     // reads in which a seam did not close: the plain walk (rare; results and class are overwritten)
     a.only_flagged = a.ch.read_fail;
-    return launch_lanes<MODE, DOC, true, NARROW, 0>(ix, a, stream);
+    if ((rc = launch_lanes<MODE, DOC, true, NARROW, 0>(ix, a, stream)) != SPX_OK) return rc;
+    return launch_len_expand(ix, a, stream);
 }
 
 }  // namespace
@@ -1424,6 +1444,103 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
         ix->last_chunk_bound = bound;
     }
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// PML lengths from the walk's reset bits (BatchArgs::len_mask).  length[p] = q - p, q = the first character at
+// or after p whose step reset the length (bit set), or the read's length when there is none: the reference's
+// `length = 0` / `length++` (compute_ms_pml.cpp:249-250, 266-276) read from the other side.  The walk writes 16
+// bytes per 128 characters instead of 2-4 bytes per character in scattered pieces (its stores cost a fifth of its
+// time, profiles/r02_store_experiments.txt); this kernel writes the lengths as a stream: groups of 8 output
+// elements aligned in memory, one 16-byte (16-bit outputs) or two (32-bit) stores each, `lpr` consecutive lanes
+// per read.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t next_reset(const uint64_t* mw, uint32_t nw, uint64_t p, uint64_t m) {
+    uint32_t w = (uint32_t)(p >> 6);
+    if (w >= nw) return m;
+    uint64_t v = mw[w] & (~0ull << (p & 63));
+    while (v == 0) {
+        if (++w >= nw) return m;
+        v = mw[w];
+    }
+    return ((uint64_t)w << 6) + (uint64_t)__builtin_ctzll(v);
+}
+
+template <bool NARROW>
+__global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, uint32_t lpr_shift) {
+    if (b.only_flagged != nullptr && b.counters->pad_ == 0) return;  // no read fell back to the plain walk
+    const uint64_t tid = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    const uint64_t rd = tid >> lpr_shift;
+    if (rd >= b.nreads) return;
+    if (b.only_flagged != nullptr && b.only_flagged[rd] == 0) return;
+    const uint32_t lpr = 1u << lpr_shift, j = (uint32_t)tid & (lpr - 1);
+    const uint64_t base = b.offs[rd], end = b.offs[rd + 1], m = end - base;
+    if (m == 0) return;
+    const uint64_t* const mw = b.len_mask + 2 * (((base - b.offs[0]) >> 7) + rd);
+    const uint32_t nw = 2 * (uint32_t)((m + 127) >> 7);
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);
+    for (uint64_t G = (base >> 3) + j; G <= ((end - 1) >> 3); G += lpr) {
+        const uint64_t glo = G * 8 < base ? base : G * 8, ghi = G * 8 + 8 > end ? end : G * 8 + 8;
+        const uint32_t cnt = (uint32_t)(ghi - glo);  // 8 but for the read's first and last group
+        const uint64_t p = glo - base;
+        const uint32_t w = (uint32_t)(p >> 6), s = (uint32_t)p & 63;
+        uint64_t bits = mw[w] >> s;  // resets of characters p .. p + 63
+        if (s != 0 && w + 1 < nw) bits |= mw[w + 1] << (64 - s);
+        uint64_t far = 0;  // first reset at or after p + 64 (only when the window holds none for the last element)
+        if ((bits >> (cnt - 1)) == 0) far = next_reset(mw, nw, p + 64, m);
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t t = bits >> i;
+            v[i] = t ? (uint32_t)__builtin_ctzll(t) : (uint32_t)(far - (p + i));
+        }
+        if (cnt == 8) {
+            if (NARROW) {
+                // (plain stores: non-temporal and write-through ones were 4-12 % slower end to end)
+                *reinterpret_cast<uint4*>(out16 + glo) =
+                    make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            } else {
+                *reinterpret_cast<uint4*>(b.out_lengths + glo) = make_uint4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint4*>(b.out_lengths + glo + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((uint32_t)i < cnt) {
+                    if (NARROW)
+                        out16[glo + i] = (uint16_t)v[i];
+                    else
+                        b.out_lengths[glo + i] = v[i];
+                }
+        }
+    }
+}
+
+int prepare_len_mask(spx_index* ix, int mode, BatchArgs& args) {
+    args.len_mask = nullptr;
+    if (mode != SPX_MODE_PML || args.out_lengths == nullptr || args.nreads == 0) return SPX_OK;
+    void* p = nullptr;
+    const int rc = chunk_scratch(ix, 8, ((args.total_chars >> 7) + args.nreads + 2) * 16, &p);
+    if (rc != SPX_OK) return rc;
+    args.len_mask = (uint64_t*)p;
+    return SPX_OK;
+}
+
+int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream) {
+    (void)ix;
+    if (args.len_mask == nullptr || args.nreads == 0) return SPX_OK;
+    // lanes per read: the power of two that covers an average read's groups of 8 (longer reads loop)
+    const uint64_t groups = args.total_chars / args.nreads / 8 + 1;
+    uint32_t lpr_shift = 0;
+    while (lpr_shift < 6 && (1ull << lpr_shift) < groups) ++lpr_shift;
+    const uint64_t threads = args.nreads << lpr_shift;
+    const unsigned grid = (unsigned)((threads + WALK_TPB - 1) / WALK_TPB);
+    if (args.narrow)
+        k_expand_lengths<true><<<grid, WALK_TPB, 0, stream>>>(args, lpr_shift);
+    else
+        k_expand_lengths<false><<<grid, WALK_TPB, 0, stream>>>(args, lpr_shift);
+    SPX_HIP(hipGetLastError());
+    return SPX_OK;
 }
 
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,

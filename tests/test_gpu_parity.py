@@ -338,3 +338,44 @@ def test_16_bit_outputs_refuse_long_reads(gpu):
     with pytest.raises(capi.SpxError):
         ix.query_host(capi.SPX_MODE_PML, seqs, offs, bits=16)
     assert ix.query_host(capi.SPX_MODE_PML, seqs, offs)["lengths"].size == 70_000
+
+
+@pytest.mark.parametrize("bits", [16, 32])
+def test_lengths_from_reset_bits_edge_shapes(gpu, oracle_mod, bits):
+    """The plain PML walk hands its lengths over as one bit per character ("the length was reset here") and
+    k_expand_lengths writes them out (compute_ms_pml.cpp:249-250, 266-276 read from the other side).  Read lengths
+    around every boundary of that encoding (64-bit words, 128-character pairs, groups of 8 outputs, reads that start
+    at any alignment), exact substrings (no reset for hundreds of characters: the scan for the next set bit crosses
+    words), substrings with one error, random reads, absent letters, empty reads."""
+    raw, text = cases.real_case(77, 30000, DNA, ndocs=2)
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 120, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 383, 384,
+            385, 1000, 1023, 1024, 1025, 5000]
+    reads = []
+    for rep in range(3):
+        for m in lens:
+            s = int(rng.integers(0, text.size - m)) if m else 0
+            exact = text[s:s + m].copy()
+            reads.append(exact)
+            one = exact.copy()
+            if m:
+                one[rng.integers(0, m)] = ord("N")  # absent letter: the length restarts at 0 there
+            reads.append(one)
+            reads.append(np.asarray(DNA, dtype=np.uint8)[rng.integers(0, 4, size=m)])
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    offs = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+    seqs = np.concatenate(reads)
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    want = orc.pml(seqs, offs)
+    ix = capi.Index.from_raw(raw, 0)
+    ix.set_option("chunk_mode", 1)  # never: this is about the plain walk
+    got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(50, 10), bits=bits)
+    assert np.array_equal(got["lengths"], want)
+    # long reset-free stretches are really there (otherwise the word-crossing scan is not exercised)
+    assert want.max() > 1000
+    _, a, b, s = oracle_mod.classify(want, offs, 50, 10)
+    assert np.array_equal(got["class"]["above"], a) and np.array_equal(got["class"]["sum_max"], s)
+    wl, wd = orc.pml(seqs, offs, want_docs=True)
+    gd = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, bits=bits)
+    assert np.array_equal(gd["lengths"], wl) and np.array_equal(gd["docs"], wd)

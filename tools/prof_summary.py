@@ -17,12 +17,15 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
         rows = list(csv.reader(open(f)))
         h = rows[0]
         kn, cn, cv = h.index("Kernel_Name"), h.index("Counter_Name"), h.index("Counter_Value")
-        agg = defaultdict(list)
-        for r in rows[1:]:
-            if "k_walk" in r[kn]:
-                agg[r[cn]].append(float(r[cv]))
-        lines.append("== rocprofv3 --pmc (%s), k_walk_lanes dispatches only: per-dispatch values" % os.path.basename(d))
-        for k, v in agg.items():
-            lines.append(f"{k}: n={len(v)} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
+        for kernel in ("k_walk_lanes", "k_expand_lengths"):
+            agg = defaultdict(list)
+            for r in rows[1:]:
+                if kernel in r[kn]:
+                    agg[r[cn]].append(float(r[cv]))
+            if not agg:
+                continue
+            lines.append("== rocprofv3 --pmc (%s), %s dispatches only: per-dispatch values" % (os.path.basename(d), kernel))
+            for k, v in agg.items():
+                lines.append(f"{k}: n={len(v)} mean={sum(v)/len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -8,12 +8,12 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/prof && mkdir -p /tmp/prof
 CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -- $CMD > $out/bench_under_rocprof.json 2>/tmp/prof/kt.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -- $CMD > $out/bench_under_rocprof.json 2>/tmp/prof/kt.log
 mv /tmp/prof/kt/*/* /tmp/prof/kt/ 2>/dev/null
 CMD2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof/pmc_fetch -- $CMD2 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof/pmc_write -- $CMD2 > /dev/null 2>&1
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d /tmp/prof/pmc_tcc -- $CMD2 > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof/pmc_fetch -- $CMD2 > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof/pmc_write -- $CMD2 > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d /tmp/prof/pmc_tcc -- $CMD2 > /dev/null 2>&1
 for d in pmc_fetch pmc_write pmc_tcc; do mv /tmp/prof/$d/*/* /tmp/prof/$d/ 2>/dev/null; done
 python tools/prof_summary.py /tmp/prof $out/summary.txt > /dev/null
 python tools/make_traffic.py /tmp/prof $out/bench_under_rocprof.json $out/traffic.json > /dev/null
