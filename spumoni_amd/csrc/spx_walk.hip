@@ -1470,6 +1470,14 @@ template <bool NARROW>
 __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, uint32_t lpr_shift) {
     if (b.only_flagged != nullptr && b.counters->pad_ == 0) return;  // no read fell back to the plain walk
     const uint64_t tid = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
+    // lanes per read from the batch's real size: the caller's total_chars, which sized the grid, may be an upper
+    // bound (reads digested on the device: DESIGN.md 4.4) -- the surplus threads leave at once
+    {
+        const uint64_t groups = (b.offs[b.nreads] - b.offs[0]) / b.nreads / 8 + 1;
+        uint32_t sh = 0;
+        while (sh < lpr_shift && (1ull << sh) < groups) ++sh;
+        lpr_shift = sh;
+    }
     const uint64_t rd = tid >> lpr_shift;
     if (rd >= b.nreads) return;
     if (b.only_flagged != nullptr && b.only_flagged[rd] == 0) return;
