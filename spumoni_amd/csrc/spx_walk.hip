@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
 // ascending counterpart of stage_n (the extension walks a read left to right): elements [i & ~(G-1), ...] of the
 // read as u16 in G / 4 registers, written as 32-bit values when the group's highest element -- or the read's
 // last -- has been produced
-template <int G>
+template <int G, bool NARROW_OUT>
 __device__ __forceinline__ void stage_up(StageN<G>& st, uint32_t value, uint32_t* out, uint64_t base, uint32_t i,
                                          bool last) {
     const uint32_t idx = i & (G - 1), r = idx >> 2;
@@ -855,6 +855,26 @@ __device__ __forceinline__ void stage_up(StageN<G>& st, uint32_t value, uint32_t
             const uint64_t lo = st.a[2 * q], hi = st.a[2 * q + 1];
             if (cnt > 8u * q) {
                 const uint32_t c = cnt - 8 * q;
+                if (NARROW_OUT) {
+                    uint16_t* p = reinterpret_cast<uint16_t*>(out) + base + (i - idx) + 8 * q;
+                    if (c >= 8) {
+                        *reinterpret_cast<H16x8*>(p) = H16x8{lo, hi};
+                    } else {
+                        uint64_t src = lo;
+                        if (c & 4) {
+                            *reinterpret_cast<H16x4*>(p) = H16x4{lo};
+                            src = hi;
+                            p += 4;
+                        }
+                        if (c & 2) {
+                            *reinterpret_cast<H16x2*>(p) = H16x2{(uint32_t)src};
+                            src >>= 32;
+                            p += 2;
+                        }
+                        if (c & 1) *p = (uint16_t)src;
+                    }
+                    continue;
+                }
                 uint32_t* p = o + 8 * q;
                 if (c >= 8) {
                     *reinterpret_cast<U32x4*>(p) = widen4(lo);
@@ -906,7 +926,6 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
     const bool live = rd < b.nreads;
     const uint64_t base = live ? b.offs[rd] : 0;
     const uint64_t m = live ? b.offs[rd + 1] - base : 0;
-    uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);  // b.narrow: 16-bit lengths
     const uint8_t* text = ix.text;
     const uint64_t n = ix.n_text;
     const bool want_class = b.out_class != nullptr;
@@ -956,10 +975,10 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
                     if (adv < 8) break;  // mismatch, or an end reached inside this word
                 }
             }
-            if (b.narrow)
-                out16[gi] = (uint16_t)l;
+            if (b.narrow)  // (m < 65536: the walk refused the batch otherwise)
+                stage_up<LEN_G, true>(obu, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
             else if (staged)
-                stage_up<LEN_G>(obu, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
+                stage_up<LEN_G, false>(obu, (uint32_t)l, b.out_lengths, base, (uint32_t)i, i + 1 == m);
             else
                 b.out_lengths[gi] = (uint32_t)l;
             if (want_class) {

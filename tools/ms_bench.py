@@ -18,8 +18,10 @@ print(f"text rebuilt from the MS index (LF chains from the SA samples): {dt*1e3:
       f"{bool(np.array_equal(ix.text(), text))}")
 d_seqs = capi.pad_seqs(torch.from_numpy(seqs).cuda()); d_offs = torch.from_numpy(offs).cuda()
 tot = nreads * m
-d_len = torch.empty(tot, dtype=torch.int32, device="cuda"); d_ptr = torch.empty(tot, dtype=torch.int64, device="cuda")
-d_doc = torch.empty(tot, dtype=torch.int32, device="cuda"); d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda")
+vt = torch.int16 if os.environ.get("MS_BENCH_BITS") == "16" else torch.int32  # 16: the entry points the CLI uses
+print("output width:", vt)
+d_len = torch.empty(tot, dtype=vt, device="cuda"); d_ptr = torch.empty(tot, dtype=torch.int64, device="cuda")
+d_doc = torch.empty(tot, dtype=vt, device="cuda"); d_cls = torch.empty((nreads, 2), dtype=torch.int64, device="cuda")
 for mode, name in ((capi.SPX_MODE_PML, "PML"), (capi.SPX_MODE_MS, "MS ")):
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
