@@ -1257,7 +1257,8 @@ int spx_last_walk_stats(spx_index* ix, spx_walk_stats* out) {
     out->dir_loads = wc.dir_loads;
     out->kernel_ms = ms;
     if (wc.error) {
-        set_error("the walk hit %llu undefined steps (inconsistent thresholds)", wc.error);
+        set_error("the walk hit %llu undefined steps (inconsistent thresholds; or a read of 65536 characters or more with "
+                  "16-bit outputs; or a batch that holds more characters than total_chars)", wc.error);
         return SPX_E_FORMAT;
     }
     return SPX_OK;

@@ -119,6 +119,7 @@ struct BatchArgs {
     // [((offs[q] - offs[0]) >> 7) + q, ...) (pairs of different reads never overlap), bit p & 63 of word p >> 6
     // for character p of the read.
     uint64_t* len_mask;
+    uint64_t len_mask_pairs;  // 16-byte pairs len_mask holds (sized from total_chars: checked, the caller may be wrong)
 };
 
 }  // namespace spx

@@ -699,8 +699,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                         mbits |= (xi & 64) ? 0 : bit;
                         mbits_hi |= (xi & 64) ? bit : 0;
                         if ((xi & 127) == 0) {
-                            *reinterpret_cast<P64x2*>(b.len_mask + 2 * (((base - base0) >> 7) + rd + (xi >> 7))) =
-                                P64x2{mbits, mbits_hi};
+                            const uint64_t pair = ((base - base0) >> 7) + rd + (xi >> 7);
+                            if (pair < b.len_mask_pairs)
+                                *reinterpret_cast<P64x2*>(b.len_mask + 2 * pair) = P64x2{mbits, mbits_hi};
+                            else
+                                n_err++;  // the batch holds more characters than the caller's total_chars
                             mbits = 0;
                             mbits_hi = 0;
                         }
@@ -1503,8 +1506,10 @@ __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, 
     const uint32_t lpr = 1u << lpr_shift, j = (uint32_t)tid & (lpr - 1);
     const uint64_t base = b.offs[rd], end = b.offs[rd + 1], m = end - base;
     if (m == 0) return;
-    const uint64_t* const mw = b.len_mask + 2 * (((base - b.offs[0]) >> 7) + rd);
+    const uint64_t pair0 = ((base - b.offs[0]) >> 7) + rd;
     const uint32_t nw = 2 * (uint32_t)((m + 127) >> 7);
+    if (pair0 + nw / 2 > b.len_mask_pairs) return;  // more characters than total_chars said: the walk reported it
+    const uint64_t* const mw = b.len_mask + 2 * pair0;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);
     for (uint64_t G = (base >> 3) + j; G <= ((end - 1) >> 3); G += lpr) {
         const uint64_t glo = G * 8 < base ? base : G * 8, ghi = G * 8 + 8 > end ? end : G * 8 + 8;
@@ -1547,9 +1552,11 @@ int prepare_len_mask(spx_index* ix, int mode, BatchArgs& args) {
     args.len_mask = nullptr;
     if (mode != SPX_MODE_PML || args.out_lengths == nullptr || args.nreads == 0) return SPX_OK;
     void* p = nullptr;
-    const int rc = chunk_scratch(ix, 8, ((args.total_chars >> 7) + args.nreads + 2) * 16, &p);
+    const uint64_t pairs = (args.total_chars >> 7) + args.nreads + 2;
+    const int rc = chunk_scratch(ix, 8, pairs * 16, &p);
     if (rc != SPX_OK) return rc;
     args.len_mask = (uint64_t*)p;
+    args.len_mask_pairs = pairs;
     return SPX_OK;
 }
 

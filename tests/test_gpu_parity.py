@@ -131,6 +131,24 @@ def test_device_resident_query_matches_host_query(gpu, oracle_mod):
     ost = orc.stats(seqs.cpu().numpy(), offs.cpu().numpy())
     assert (st["steps"], st["jumps"], st["pred_jumps"]) == (ost["steps"], ost["jumps"], ost["pred_jumps"])
     assert st["kernel_ms"] > 0
+    # total_chars may be an upper bound (reads digested on the device) ...
+    d_len.zero_()
+    ix.query_device(capi.SPX_MODE_PML, d_seqs, offs, 3 * seqs.numel() + 1000, d_lengths=d_len, d_class=d_cls,
+                    bin_width=150, max_value_thr=5)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_len.cpu().numpy().view(np.uint32), want)
+    ix.last_stats()
+    # ... but not less than the batch holds: it sizes the walk's scratch, and the walk says so instead of writing
+    # past it
+    ix.query_device(capi.SPX_MODE_PML, d_seqs, offs, seqs.numel() // 8, d_lengths=d_len, d_class=d_cls, bin_width=150,
+                    max_value_thr=5)
+    torch.cuda.synchronize()
+    with pytest.raises(capi.SpxError, match="total_chars"):
+        ix.last_stats()
+    ix.query_device(capi.SPX_MODE_PML, d_seqs, offs, seqs.numel(), d_lengths=d_len, d_class=d_cls, bin_width=150,
+                    max_value_thr=5)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_len.cpu().numpy().view(np.uint32), want) and ix.last_stats()["steps"] == ost["steps"]
 
 
 def test_raw_file_loader(gpu, oracle_mod, tmp_path):
