@@ -65,7 +65,9 @@ typedef struct spx_walk_stats {
     uint64_t pred_jumps;
     uint64_t row_loads;   /* landing-row loads (>= steps)                      */
     uint64_t dir_loads;   /* per-letter directory loads (count table + window) */
-    float kernel_ms;      /* HIP-event time of the walk kernel, last query     */
+    float kernel_ms;      /* HIP-event time of the walk of the last query (the
+                             kernel(s) that search; not the pass that writes the
+                             PML lengths out, nor the MS length extension)      */
 } spx_walk_stats;
 
 const char *spx_last_error(void);
