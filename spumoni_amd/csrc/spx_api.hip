@@ -703,6 +703,18 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         }
     }
     hipStream_t s_in = ix->pipe_s[0], s_k = ix->pipe_s[1], s_out = ix->pipe_s[2];
+    if (mode == SPX_MODE_PML && out_lengths) {
+        // the length-bit scratch is sized for the largest piece BEFORE the pipeline starts: growing it between
+        // pieces would hipFree (an implicit device synchronisation) in the middle of the copy / compute overlap
+        uint64_t worst = 0;
+        for (int c = 0; c < NCH; ++c) {
+            const uint64_t q0 = nreads * c / NCH, q1 = nreads * (c + 1) / NCH;
+            const uint64_t pairs = ((offsets[q1] - offsets[q0]) >> 7) + (q1 - q0) + 2;
+            worst = pairs > worst ? pairs : worst;
+        }
+        void* unused = nullptr;
+        if ((rc = chunk_scratch(ix, 8, worst * 16, &unused)) != SPX_OK) return rc;
+    }
     if (ix->have_timing && ix->last_stream != s_k) SPX_HIP(hipStreamWaitEvent(s_k, ix->ev_done, 0));
     SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), s_k));
     SPX_HIP(hipEventRecord(ix->ev0, s_k));
@@ -733,7 +745,7 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         if ((rc = prepare_len_mask(ix, mode, args)) != SPX_OK) return rc;
         {  // a chunk of few, long reads is cut further and walked chunk-wise (spx_walk.hip)
             bool chunked = false;
-            if ((rc = launch_walk_chunked(ix, mode, args, b - a, s_k, &chunked, a)) != SPX_OK) return rc;
+            if ((rc = launch_walk_chunked(ix, mode, args, b - a, s_k, &chunked)) != SPX_OK) return rc;
             if (!chunked && ((rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK ||
                              (rc = launch_len_expand(ix, args, s_k)) != SPX_OK))
                 return rc;

@@ -237,7 +237,7 @@ int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // long-read batches: the chunked walk (returns SPX_OK and sets *done = false when the batch does not
 // qualify and the plain walk should run)
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
-                        bool* done, uint64_t gi_base = 0);
+                        bool* done);
 // spx_digest.hip: d_out_offs gets nreads + 1 offsets, d_out the digested reads (capacity is the
 // caller's business: spx_digest_capacity)
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,

@@ -276,6 +276,11 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     uint32_t rflag = 0;      // what the current step reset: bit 0 length / sample, bit 1 document id
     uint64_t fb = 0;         // pass 1: flags of the aligned group of 8 characters, a byte each
     uint32_t item_rd = 0, item_flags = 0, seen = 0, ph_after = P_LAND, tlimit = 0xffffffffu;
+    // the chunk scratch is indexed by character index relative to the batch's first character: offsets are
+    // absolute (a piece of a larger batch, or a caller whose offsets[0] != 0), the scratch is sized by total_chars
+    const uint64_t ch_org = CHUNK ? b.offs[0] : 0;
+    uint8_t* const ch_flags = CHUNK ? b.ch.flags - (ch_org & ~7ull) : nullptr;
+    WalkState* const ch_ckpt = CHUNK ? b.ch.ckpt - (ch_org >> CKPT_SHIFT) : nullptr;
     if (rd >= nitems || (threadIdx.x & 63) >= lpw) ph = P_DONE;
 #define STAND_ON(row)                                \
     do {                                             \
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             // round 1: the recorded end state of the chunk above (the next one); later: what the scan left
             p0 = reinterpret_cast<const char*>(b.ch.round > 1 ? b.ch.reentry + rd : b.ch.ends + rd + 1);
         } else if (CHUNK == 2 && ph == P_CKPT) {
-            p0 = reinterpret_cast<const char*>(b.ch.ckpt + ((base + x) >> CKPT_SHIFT));
+            p0 = reinterpret_cast<const char*>(ch_ckpt + ((base + x) >> CKPT_SHIFT));
         } else if (MODE == SPX_MODE_MS && ph == P_SAMP) {
             p0 = reinterpret_cast<const char*>(ix.ss_by_run + k);
         } else {
@@ -657,18 +662,18 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 // which counters this step reset: what pass 3 needs to know where a wrong start value ends
                 seen |= rflag;
                 if (CHUNK == 2) {
-                    b.ch.flags[gi] = (uint8_t)rflag;
+                    ch_flags[gi] = (uint8_t)rflag;
                 } else {
                     const uint32_t slot = (uint32_t)gi & 7;
                     fb |= (uint64_t)rflag << (slot * 8);
                     if (slot == 0 || xi == 0) {
                         const uint64_t g8 = gi & ~7ull;
                         if (g8 >= base && g8 + 7 < base + m) {
-                            *reinterpret_cast<uint64_t*>(b.ch.flags + g8) = fb;
+                            *reinterpret_cast<uint64_t*>(ch_flags + g8) = fb;
                         } else {
 #pragma unroll
                             for (int t = 0; t < 8; ++t)
-                                if (g8 + t >= gi && g8 + t < base + m) b.ch.flags[g8 + t] = (uint8_t)(fb >> (t * 8));
+                                if (g8 + t >= gi && g8 + t < base + m) ch_flags[g8 + t] = (uint8_t)(fb >> (t * 8));
                         }
                         fb = 0;
                     }
@@ -807,7 +812,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
                 // checkpoint: the state before character base + x - 1
                 if (CHUNK == 1) {
-                    b.ch.ckpt[(base + x) >> CKPT_SHIFT] =
+                    ch_ckpt[(base + x) >> CKPT_SHIFT] =
                         WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                 } else {
                     ph_after = ph;
@@ -1215,6 +1220,7 @@ __global__ void k_chunk_fix(const BatchArgs b) {
     if (ce - cs < 2 || b.ch.read_fail[q]) return;
     uint16_t* const len16 = reinterpret_cast<uint16_t*>(b.out_lengths);
     uint16_t* const doc16 = reinterpret_cast<uint16_t*>(b.out_docs);
+    const uint8_t* const ch_flags = b.ch.flags - (b.offs[0] & ~7ull);  // as in the walk: relative to the batch
     // corrections carried into the results of the walk that enters the next chunk down: its start
     // values were the recorded end values of the chunk above, which are off by this much
     bool c_on = false, cd_on = false;
@@ -1229,7 +1235,7 @@ __global__ void k_chunk_fix(const BatchArgs b) {
         for (uint64_t i = from; i-- > to;) {
             if ((i & ~7ull) != have) {
                 have = i & ~7ull;
-                w8 = *reinterpret_cast<const uint64_t*>(b.ch.flags + have);
+                w8 = *reinterpret_cast<const uint64_t*>(ch_flags + have);
             }
             const uint32_t f = (uint32_t)(w8 >> ((i & 7) * 8)) & 0xffu;
             if (!cnt_reset) {
@@ -1358,10 +1364,11 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
 
 // Long-read batches (BASELINE config 5: 50 000 x 10 kbp, 6 250 per GPU): fewer reads than the chip has
 // lanes.  Cut them into chunks and walk the chunks (spx_internal.h).  *done = false: not such a batch.
-// gi_base: the batch's characters are seqs[gi_base, gi_base + total_chars) (offsets are absolute: a piece of a
-// larger host batch starts where the piece before it ended)
+// Offsets are absolute (a piece of a larger host batch starts where the piece before it ended; a caller's
+// offsets[0] need not be 0): the kernels index the per-character scratch relative to offs[0], which they read
+// from device memory.
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
-                        bool* done, uint64_t gi_base) {
+                        bool* done) {
     *done = false;
     ix->last_chunk_len = ix->last_chunk_bound = 0;
     if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
@@ -1430,11 +1437,11 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     a.ch.desc = (const ChunkDesc*)p_desc;
     a.ch.nchunks = nchunks;
     a.ch.ends = (WalkState*)p_ends;
-    a.ch.ckpt = (WalkState*)p_ckpt - (gi_base >> CKPT_SHIFT);  // indexed by character index >> CKPT_SHIFT
+    a.ch.ckpt = (WalkState*)p_ckpt;  // indexed by (character index >> CKPT_SHIFT) - (offs[0] >> CKPT_SHIFT)
     a.ch.seams = (SeamRec*)p_seams;
     // indexed by character index; flags are read and written in aligned groups of 8, so the origin is moved by a
     // multiple of 8 and a group in front of the first character stays inside the buffer
-    a.ch.flags = (uint8_t*)p_flags + 8 - (gi_base & ~7ull);
+    a.ch.flags = (uint8_t*)p_flags + 8;
     a.ch.read_fail = (uint32_t*)p_fail;
     a.ch.chunk_start = chunk_start;
     a.ch.reentry = (WalkState*)p_ends + (bound + 1);

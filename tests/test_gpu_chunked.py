@@ -168,3 +168,45 @@ def test_pipelined_host_batch_pieces_take_the_chunked_walk(oracle_mod):
     orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
     wl, wd = orc.pml(seqs[: offs[ns]], offs[: ns + 1], want_docs=True)
     assert np.array_equal(want["lengths"][: offs[ns]], wl) and np.array_equal(want["docs"][: offs[ns]], wd)
+
+
+@pytest.mark.parametrize("shift_by", [1, 16, 37, 4099])
+@pytest.mark.parametrize("mode_doc", [(0, False), (0, True), (1, True)])
+def test_device_path_with_nonzero_first_offset(oracle_mod, shift_by, mode_doc):
+    """spx_query_batch_device with d_offsets[0] != 0 (the header allows it: total_chars =
+    d_offsets[nreads] - d_offsets[0]) on the chunked walk: the per-character scratch (flag bytes,
+    checkpoints) is sized by total_chars, so the kernels index it relative to offs[0]."""
+    mode, doc = mode_doc
+    raw = synth.statistical_rlbwt(1 << 15, 253, 6.0, seed=8, device="cuda", zipf=1.0, with_samples=True, n_docs=6)
+    seqs, offs = synth.simulate_reads(raw, 60, 1700, seed=18, warmup=2)
+    total = int(seqs.numel())
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    hs, ho = seqs.cpu().numpy(), offs.cpu().numpy()
+    ix = _chunked(capi.Index.from_raw(raw, 0), 7)
+    # the same reads, preceded by `shift_by` bytes that belong to no read
+    d_seqs = torch.zeros(shift_by + total + 64, dtype=torch.uint8, device="cuda")
+    d_seqs[shift_by: shift_by + total] = seqs
+    d_offs = (offs + shift_by).contiguous()
+    d_len = torch.full((shift_by + total + 8,), -1, dtype=torch.int32, device="cuda")
+    d_ptr = torch.full((shift_by + total + 8,), -1, dtype=torch.int64, device="cuda") if mode == 1 else None
+    d_doc = torch.full((shift_by + total + 8,), -1, dtype=torch.int32, device="cuda") if doc else None
+    d_cls = torch.zeros((60, 2), dtype=torch.int64, device="cuda") if mode == 0 else None
+    ix.query_device(mode, d_seqs, d_offs, total, d_lengths=d_len if mode == 0 else None, d_pointers=d_ptr, d_docs=d_doc,
+                    d_class=d_cls, bin_width=150, max_value_thr=5)
+    torch.cuda.synchronize()
+    assert ix.last_chunk_stats()["chunk_len"] == 128
+    sl = slice(shift_by, shift_by + total)
+    if mode == 0:
+        want = orc.pml(hs, ho, want_docs=doc)
+        lens, docs = want if doc else (want, None)
+        assert np.array_equal(d_len[sl].cpu().numpy().view(np.uint32), lens)
+        assert bool((d_len[:shift_by] == -1).all())  # nothing written in front of the first read
+        if doc:
+            assert np.array_equal(d_doc[sl].cpu().numpy().view(np.uint32), docs)
+        f, a, b, ssum = oracle_mod.classify(lens, ho, 150, 5)
+        cls = d_cls.cpu().numpy().view(capi.CLASS_DTYPE).reshape(-1)
+        assert np.array_equal(cls["above"], a) and np.array_equal(cls["below"], b)
+    else:
+        want = orc.ms(hs, ho, want_docs=True)
+        assert np.array_equal(d_ptr[sl].cpu().numpy().view(np.uint64), want["pointers"])
+        assert np.array_equal(d_doc[sl].cpu().numpy().view(np.uint32), want["docs"])
