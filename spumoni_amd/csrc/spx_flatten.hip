@@ -170,7 +170,11 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
             const uint64_t nx = dst + 1 + t;
             acc = (acc >= CUM_SAT || nx >= r) ? CUM_SAT : acc + (S[nx + 1] - S[nx]);
         }
-        rows[k] = pack_row_compact(c, (uint32_t)lens[k], (uint32_t)dst, (uint32_t)soff, thr <= S[k], cum);
+        // a compact index keeps its rows 32 bytes apart (Row32); the second half is filled in by k_embed_rows
+        const Row cr = pack_row_compact(c, (uint32_t)lens[k], (uint32_t)dst, (uint32_t)soff, thr <= S[k], cum);
+        Row32* r32 = reinterpret_cast<Row32*>(rows) + k;
+        r32->q0 = cr.q0;
+        r32->q1 = cr.q1;
     } else {
         rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
     }
@@ -197,9 +201,42 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
 __global__ void k_sentinel_rows(Row* rows, uint64_t r, int compact) {
     int t = threadIdx.x;
     const uint32_t sat[4] = {CUM_SAT, CUM_SAT, CUM_SAT, CUM_SAT};
-    if (t < ROW_PAD)
-        rows[r + t] = compact ? pack_row_compact(0, 0xffff, (uint32_t)r, 0, true, sat)
-                              : pack_row(0, MASK40, (uint32_t)r, 0, true, ROOM_SAT);
+    if (t < ROW_PAD) {
+        if (compact) {
+            const Row cr = pack_row_compact(0, 0xffff, (uint32_t)r, 0, true, sat);
+            reinterpret_cast<Row32*>(rows)[r + t] = Row32{cr.q0, cr.q1, 0, 0};
+        } else {
+            rows[r + t] = pack_row(0, MASK40, (uint32_t)r, 0, true, ROOM_SAT);
+        }
+    }
+}
+
+// Second half of the compact rows (spx_layout.h, Row32): the row of the likeliest destination run D = LFrun and
+// the heads of the other destinations, copied next to the row that points to them.  One thread per run, after
+// k_build_rows / k_sentinel_rows (reads the first halves, writes the second: no race).  Hrun: heads by run index.
+__global__ void k_embed_rows(Row* rows, const uint8_t* Hrun, uint64_t r) {
+    const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (k >= r + ROW_PAD) return;
+    Row32* r32 = reinterpret_cast<Row32*>(rows);
+    Row own;
+    own.q0 = r32[k].q0;
+    own.q1 = r32[k].q1;
+    const uint64_t D = crow_LFrun(own);
+    auto head = [&](uint64_t run) -> uint32_t { return run < r ? Hrun[run] : 0u; };
+    Row d;
+    d.q0 = r32[D < r + ROW_PAD ? D : r].q0;
+    d.q1 = r32[D < r + ROW_PAD ? D : r].q1 & ~0xffff0000ull;  // (h1 / h2 of row D may or may not be there yet)
+    const uint64_t DD = crow_LFrun(d);
+    const uint32_t dh[4] = {head(DD), head(DD + 1), head(DD + 2), head(DD + 3)};
+    Row32 out = r32[k];
+    out.q1 &= ~0xffff0000ull;
+    // an embedded row is only stood on when the walk lands in a real run: D >= r (the "pos == n" sentinel) keeps
+    // its zero head, which no character matches
+    row32_embed(out, d, head(D + 1), head(D + 2), dh);
+    if (D >= r) out.e0 &= ~(0xffull << 16);
+    r32[k].q1 = out.q1;
+    r32[k].e0 = out.e0;
+    r32[k].e1 = out.e1;
 }
 
 __global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* out) {
@@ -442,8 +479,6 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
 
     // rows + jump rows
     const bool docs = d_ds && d_de;
-    SPX_ALLOC0(ix->rows, (r + ROW_PAD) * sizeof(Row));
-    SPX_ALLOC0(ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow));
     DevBuf dirdocs_tmp;  // by directory position j: docS[Q[j]] | docE[Q[j-1]] << 16; packed into aux below
     if (docs) {
         SPX_HIP(dirdocs_tmp.alloc((r + ROW_PAD) * 4));
@@ -459,6 +494,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(hipStreamSynchronize(st));
     }
     const int compact = (max_len < 65536 && !getenv("SPX_ROWS_WIDE")) ? 1 : 0;
+    const uint64_t row_bytes = compact ? sizeof(Row32) : sizeof(Row);
+    SPX_ALLOC0(ix->rows, (r + ROW_PAD) * row_bytes);
+    SPX_ALLOC0(ix->dirrows, (r + ROW_PAD) * sizeof(JumpRow));
     k_build_rows<<<nblocks(r), TPB, 0, st>>>(Qall.as<uint32_t>(), Hs.as<uint8_t>(), LFs.as<uint64_t>(),
                                               S.as<uint64_t>(), d_lens, nzpos.as<uint32_t>(),
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters,
@@ -466,6 +504,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                               docs ? dirdocs_tmp.as<uint32_t>() : nullptr,
                                               ix->rundocs, err.as<unsigned long long>());
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, compact);
+    if (compact) k_embed_rows<<<nblocks(r + ROW_PAD), TPB, 0, st>>>(ix->rows, H.as<uint8_t>(), r);
     SPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(T.p);
     T.p = nullptr;
@@ -490,8 +529,8 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     const uint32_t fat_row_bytes = sizeof(FatRow);
     const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs) ? (uint32_t)sizeof(Aux) : 0);
     const double per_slot = fat_stride + 4 /* fat_j */;
-    // per-run arrays: rows 16 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
-    const double fixed = (double)r * (16 + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));
+    // per-run arrays: rows 16 / 32 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
+    const double fixed = (double)r * ((double)row_bytes + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));
     // still to be allocated from the free memory besides the fat table: Q, aux, ss_by_run and the
     // sample pairs scratch
     const double to_come = (double)r * (4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 + 16 : 0)) + (64 << 20);
@@ -550,7 +589,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     SPX_ALLOC0(ix->q_alloc, (r + 1 + Q_PAD) * 4);
     k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
                                                                          ix->q_alloc);
-    uint64_t bytes = (r + ROW_PAD) * (sizeof(Row) + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
+    uint64_t bytes = (r + ROW_PAD) * (row_bytes + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
                      (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 4 : 0);
     uint64_t last_esa = 0, last_de = 0, first_ds = 0;
     DevBuf samples_tmp;
@@ -601,7 +640,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.fat_stride = fat_stride;
     ix->n_text = 0;
     bind_view(ix);
-    ix->arr_bytes[A_ROWS] = (r + ROW_PAD) * sizeof(Row);
+    ix->arr_bytes[A_ROWS] = (r + ROW_PAD) * row_bytes;
     ix->arr_bytes[A_DIRROWS] = (r + ROW_PAD) * sizeof(JumpRow);
     ix->arr_bytes[A_FAT] = (nfat + 2) * (uint64_t)fat_stride;
     ix->arr_bytes[A_FATJ] = nfat * 4 + 64;
@@ -618,7 +657,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     v.nfat = nfat;
     v.init_k = (uint32_t)(r - 1);
     v.init_off = last_len - 1;
-    SPX_HIP(hipMemcpy(&v.init_row, ix->rows + (r - 1), sizeof(Row), hipMemcpyDeviceToHost));
+    memset(&v.init_row, 0, sizeof v.init_row);
+    SPX_HIP(hipMemcpy(&v.init_row, reinterpret_cast<const char*>(ix->rows) + (r - 1) * row_bytes, row_bytes,
+                      hipMemcpyDeviceToHost));
     v.init_sample = ix->has_samples ? (last_esa + 1) % n : 0;
     v.init_doc = (uint32_t)last_de;
     v.doc_at0 = (uint32_t)first_ds;

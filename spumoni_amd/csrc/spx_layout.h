@@ -45,7 +45,7 @@
 // Names the flat layout AND the walk kernels that read it: a .spx cache written by another layout is
 // refused, and measured HBM traffic (profiles/traffic.json) is only quoted for the version it was
 // taken with.  Bump on any change to a record in this file or to the walk's access pattern.
-#define SPX_LAYOUT_VERSION "spx-flat-r02f"
+#define SPX_LAYOUT_VERSION "spx-flat-r03a"
 
 namespace spx {
 
@@ -101,12 +101,39 @@ SPX_HD Row pack_row_compact(uint32_t H, uint32_t len, uint32_t LFrun, uint32_t L
     r.q1 = (uint64_t)(H & 0xff) | ((uint64_t)(thr_ok ? 1 : 0) << 8) | (c << 32);
     return r;
 }
+// A compact index stores its rows as Row32 (32 bytes, 32-byte aligned: one 128-byte line, two 16-byte lane
+// loads): the compact row of run k, the heads of the runs a step from k can land in, and -- embedded -- what
+// the walk needs to STAND on the likeliest of them, run D = LFrun, without fetching D's own row:
+//     q0: as above                       q1: H[8] | thr_ok << 8 | h1[8] << 16 | h2[8] << 24 | cums << 32
+//     e0: D.LFoff[16] | D.H[8] << 16 | D.thr_ok << 24 | D.LFrun[32] << 32
+//     e1: D.cums[32] | heads of runs D.LFrun, D.LFrun+1, D.LFrun+2, D.LFrun+3 [8 each] << 32
+// h1, h2 = heads of runs LFrun+1, LFrun+2 (0 = unknown / past the last run; a head is never 0 after the
+// terminator rewrite).  A match step from (k, off) whose destination is exactly (LFrun, LFoff + off) -- cum0 > off,
+// half of the match steps on the statistical bench index, more on a real BWT -- goes on from the embedded row
+// at once: two LF steps per gather.  And whichever run a step lands in, if its head is known and the next
+// character differs from it, the next step is a jump, which needs only (run, offset): the landing row is not
+// fetched at all (what the jump rows' Hs does for landings after a jump).  tools/layout_sim.py: row gathers per
+// character 0.91 -> 0.50 on match-heavy reads, 0.46 -> 0.25 on the bench mix.
+struct alignas(32) Row32 {
+    uint64_t q0, q1, e0, e1;
+};
 SPX_HD uint32_t crow_len(const Row& r) { return (uint32_t)r.q0 & 0xffff; }
 SPX_HD uint32_t crow_LFoff(const Row& r) { return ((uint32_t)r.q0 >> 16) & 0xffff; }
 SPX_HD uint32_t crow_LFrun(const Row& r) { return (uint32_t)(r.q0 >> 32); }
 SPX_HD uint32_t crow_H(const Row& r) { return (uint32_t)r.q1 & 0xff; }
 SPX_HD bool crow_thr_ok(const Row& r) { return (r.q1 >> 8) & 1; }
 SPX_HD uint32_t crow_cums(const Row& r) { return (uint32_t)(r.q1 >> 32); }
+// heads of the destination runs LFrun, LFrun+1, LFrun+2, (unknown) of a full Row32, a byte each
+SPX_HD uint32_t row32_dheads(const Row32& r) {
+    return ((uint32_t)(r.e0 >> 16) & 0xffu) | (((uint32_t)(r.q1 >> 16) & 0xffffu) << 8);
+}
+SPX_HD void row32_embed(Row32& r, const Row& d, uint32_t h1, uint32_t h2, const uint32_t dh[4]) {
+    r.q1 |= ((uint64_t)(h1 & 0xff) << 16) | ((uint64_t)(h2 & 0xff) << 24);
+    r.e0 = (uint64_t)crow_LFoff(d) | ((uint64_t)crow_H(d) << 16) | ((uint64_t)(crow_thr_ok(d) ? 1 : 0) << 24) |
+           ((uint64_t)crow_LFrun(d) << 32);
+    r.e1 = (uint64_t)crow_cums(d) | ((uint64_t)((dh[0] & 0xff) | ((dh[1] & 0xff) << 8) | ((dh[2] & 0xff) << 16) |
+                                                ((dh[3] & 0xff) << 24)) << 32);
+}
 
 struct alignas(32) JumpRow {
     uint64_t d0;  // q[32] | THRrun[32] << 32
@@ -213,7 +240,7 @@ struct SamplePair {  // flatten-time temporary: entry j = {samples_start[Q[j]], 
 
 // kernel-visible view of an index (all pointers are device memory)
 struct DevIndex {
-    const Row* rows;            // r + ROW_PAD rows; row r is the "pos == n" sentinel
+    const Row* rows;            // r + ROW_PAD rows (Row32 when compact: stride 32 bytes); row r is the "pos == n" sentinel
     const JumpRow* dirrows;     // r + 1 (+ pad) jump rows, (letter, run) order
     const char* fat;            // slots of the first c-run at or after a block, letter by letter (see fat_stride)
     const uint32_t* Q;          // directory; Q[-1] and Q[r .. r + Q_PAD) are readable
@@ -235,10 +262,15 @@ struct DevIndex {
     uint64_t nfat;      // fat slots in all (every letter: fat_block(r, bmul) + 2)
     uint32_t init_k;    // run of position n-1  (= r-1)
     uint64_t init_off;  // (n-1) - S[r-1]
-    Row init_row;       // rows[r-1]: every read starts on it, so the walk never gathers it
+    Row32 init_row;     // rows[r-1]: every read starts on it, so the walk never gathers it (general rows: q0, q1)
     uint64_t init_sample;  // get_last_run_sample(): (samples_last[r-1] + 1) % n
     uint32_t init_doc;     // end_runs_doc[r-1]         (compute_ms_pml.cpp:298)
     uint32_t doc_at0;      // start_runs_doc[run_of_position(0)]   (:641-642)
 };
+
+// row k of an index in either encoding (the first 16 bytes of a Row32 are the compact Row)
+SPX_HD const Row& row_at(const DevIndex& ix, uint64_t k) {
+    return *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(ix.rows) + k * (ix.compact ? sizeof(Row32) : sizeof(Row)));
+}
 
 }  // namespace spx

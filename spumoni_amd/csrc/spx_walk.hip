@@ -52,7 +52,8 @@ enum : uint32_t {
     P_FATJ = 8,
     P_DONE = 9,
     P_START = 10,  // chunked walk, pass 2: the end state of the chunk above
-    P_CKPT = 11    // chunked walk, pass 2: the speculative walk's state at a checkpoint
+    P_CKPT = 11,   // chunked walk, pass 2: the speculative walk's state at a checkpoint
+    P_STEP = 12    // standing on a row already (the embedded one): nothing to fetch, look at the next character
 };
 
 constexpr int WALK_TPB = 256;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void lf_target(uint32_t LFrun, OFFS LFoff, uint32_t r
 // unless it lies further than that.
 template <class OFFS>
 __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t cums, OFFS off, uint32_t& k0,
-                                            OFFS& offp) {
+                                            OFFS& offp, uint32_t& t_out) {
     const uint32_t o = off < 126 ? (uint32_t)off : 126u;
     // byte i gets its top bit iff cum_i <= o (no borrows: every byte of the minuend is >= 128)
     const uint32_t flags = (((o * 0x01010101u) | 0x80808080u) - cums) & 0x80808080u;
@@ -99,6 +100,9 @@ __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t
     const uint32_t prev = (cums >> (8 * ((t + 3) & 3))) & 0x7fu;  // cum_{t-1} (unused when t == 0)
     k0 = LFrun + t;
     offp = t ? off - prev : LFoff + off;
+    // the landing is exact -- the step ends in run LFrun + t, no row to skip -- when the bounding cum is a true
+    // value: t < 4 and off below the saturation mark; 4 = "not known"
+    t_out = (t < 4 && off <= 126) ? t : 4u;
 }
 
 // Output staging.  A lane's stores go to its own read: 64 lanes, 64 different cache lines per store
@@ -252,6 +256,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // jump bookkeeping
     uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0, Hland = 0;
     bool quirk = false, peek = false;
+    // compact rows (Row32, spx_layout.h): the embedded row of the likeliest destination run, and the heads of
+    // the runs a step from here can land in (a byte each, 0 = not known)
+    uint64_t e0 = 0, e1 = 0;
+    bool emb_ok = false, stand = false;
+    uint32_t dheads = 0, tt = 4;
+    constexpr uint32_t ROW_STRIDE = COMPACT ? sizeof(Row32) : sizeof(Row);
     // character window: the 32 bytes of the read starting at byte offset wbase of seqs, kept in LDS
     // as [dword j of the window][thread] (conflict-free) -- eight registers and a select chain less
     // than holding it in VGPRs (90 -> 72 registers, DNA walks +7 %)
@@ -307,12 +317,21 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         rd += nlanes;                             \
         ph = rd < nitems ? P_READ : P_DONE;       \
     } while (0)
+// LF of (k, off) and, for compact rows, what is known about the landing before any gather: the walk goes on from
+// the embedded row when the step ends exactly in run LFrun (stand), or knows the head of the run it ends in (peek)
 #define LF_TARGET()                                                      \
     do {                                                                 \
-        if (COMPACT)                                                     \
-            lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp);        \
-        else                                                             \
+        if (COMPACT) {                                                   \
+            lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp, tt);    \
+            if (tt == 0 && emb_ok) {                                     \
+                stand = true;                                            \
+            } else if (tt < 4) {                                         \
+                Hland = (dheads >> (8 * tt)) & 0xffu;                    \
+                peek = Hland != 0;                                       \
+            }                                                            \
+        } else {                                                         \
             lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);          \
+        }                                                                \
     } while (0)
 
     while (ph != P_DONE) {
@@ -320,7 +339,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         const char* p0;
         uint64_t fidx = 0;  // fat-table slot (P_FAT only)
         if (ph == P_LAND) {
-            p0 = rows_b + (uint64_t)k0 * sizeof(Row);
+            p0 = rows_b + (uint64_t)k0 * ROW_STRIDE;
         } else if (ph == P_FAT) {
             fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
             p0 = fat_b + fidx * ix.fat_stride;
@@ -345,7 +364,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else {
             p0 = rows_b;
         }
-        const bool wide = (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS) | (CHUNK == 2 && (ph == P_START || ph == P_CKPT));
+        const bool wide = (COMPACT && ph == P_LAND) | (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS) |
+                          (CHUNK == 2 && (ph == P_START || ph == P_CKPT));
         const V16 ga = *reinterpret_cast<const V16*>(p0);
         V16 gb{0, 0, 0, 0};
         if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
@@ -386,8 +406,16 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 k = k0;
                 off = offp;
                 STAND_ON(ra);
+                if (COMPACT) {
+                    e0 = g2;
+                    e1 = g3;
+                    emb_ok = true;
+                    dheads = ((uint32_t)(g2 >> 16) & 0xffu) | (((uint32_t)(g1 >> 16) & 0xffffu) << 8);
+                }
                 do_step = true;
             }
+        } else if (ph == P_STEP) {
+            do_step = true;
         } else if (ph == P_FAT) {
             n_dir++;
             const uint32_t hq = (uint32_t)g0;
@@ -507,7 +535,18 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 // kernel arguments -- the walk stands on it at once and fetches its first characters
                 k = ix.init_k;
                 off = (offs_t)ix.init_off;
-                STAND_ON(ix.init_row);
+                {
+                    Row ir;
+                    ir.q0 = ix.init_row.q0;
+                    ir.q1 = ix.init_row.q1;
+                    STAND_ON(ir);
+                    if (COMPACT) {
+                        e0 = ix.init_row.e0;
+                        e1 = ix.init_row.e1;
+                        emb_ok = true;
+                        dheads = row32_dheads(ix.init_row);
+                    }
+                }
                 {
                     const uint64_t end4 = (base + m + 3) & ~3ull;  // window ends past the last character
                     wbase = end4 >= 32 ? end4 - 32 : 0;
@@ -604,6 +643,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             }
         }
 
+        // Step and emit, up to twice per gather: a step that ends exactly in the run whose row came embedded in
+        // the row the walk stood on goes on from there (spx_layout.h, Row32) -- two LF steps for one gather.
+        bool again;
+#pragma clang loop unroll(disable)
+        do {
+        again = false;
         if (do_step) {
             // next character: auto c = pattern[m - i - 1]   (:247)
             const uint64_t g = base + x - 1;
@@ -783,7 +828,20 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 NEXT_ITEM();
             } else {
                 ph = P_LAND;
-                if (peek) {
+                if (COMPACT && stand) {
+                    // the step ended in run LFrun, whose row travelled with the row the walk stood on
+                    k = k0;
+                    off = offp;
+                    H_k = (uint32_t)(e0 >> 16) & 0xffu;
+                    thr_ok_k = (e0 >> 24) & 1;
+                    LFoff_k = (offs_t)((uint32_t)e0 & 0xffffu);
+                    LFrun_k = (uint32_t)(e0 >> 32);
+                    room_k = (uint32_t)e1;
+                    dheads = (uint32_t)(e1 >> 32);
+                    emb_ok = false;
+                    ph = P_STEP;
+                    again = true;
+                } else if (peek) {
                     // The jump row told us the head of the run we land in.  If the next character
                     // is present in the index and differs from it, the next step is a jump again
                     // -- from (k0, offp), which is all a jump needs -- and the landing row is
@@ -797,6 +855,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                             k = k0;
                             off = offp;
                             H_k = Hland;
+                            emb_ok = false;
                             c = cn;
                             quirk = false;
                             qbeg = li.qbeg;
@@ -809,17 +868,22 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 }
             }
             peek = false;
+            stand = false;
             if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
                 // checkpoint: the state before character base + x - 1
                 if (CHUNK == 1) {
                     ch_ckpt[(base + x) >> CKPT_SHIFT] =
                         WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                 } else {
-                    ph_after = ph;
+                    ph_after = ph;  // (P_STEP: the walk goes on from the embedded row after the comparison)
                     ph = P_CKPT;
+                    again = false;
                 }
             }
         }
+        do_step = again;
+        do_emit = false;
+        } while (COMPACT && again);
         // One flat loop, one back edge.  Hiding the phase from the optimiser here keeps it from
         // threading the "read finished" path into a back edge of its own and splitting the loop
         // into an outer per-read and an inner per-character loop -- in which every lane waits at
@@ -1024,7 +1088,7 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
 __global__ void k_text_check(const DevIndex ix, unsigned long long* bad) {
     const uint64_t k = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
     if (k >= ix.r) return;
-    const Row row = ix.rows[k];
+    const Row row = row_at(ix, k);
     const uint32_t H = ix.compact ? crow_H(row) : row_H(row);
     const uint64_t s = ix.ss_by_run[k];
     const bool ok = s < ix.n_text ? ix.text[s] == H : (s == ix.n - 1 && H <= 1);
@@ -1047,14 +1111,14 @@ __global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_t
     uint32_t k = (uint32_t)k_start;
     uint64_t off = 0;
     for (uint64_t guard = 0;; ++guard) {
-        const Row row = ix.rows[k];
+        const Row row = row_at(ix, k);
         const uint32_t H = ix.compact ? crow_H(row) : row_H(row);
         if (t < n_text) text[t] = (uint8_t)H;
         // LF of (k, off): run LFrun at offset LFoff + off, or a later run when that overshoots
         uint32_t k0 = ix.compact ? crow_LFrun(row) : row_LFrun(row);
         uint64_t offp = (ix.compact ? (uint64_t)crow_LFoff(row) : row_LFoff(row)) + off;
         for (;;) {
-            const Row r0 = ix.rows[k0];
+            const Row r0 = row_at(ix, k0);
             const uint64_t len = ix.compact ? (uint64_t)crow_len(r0) : row_len(r0);
             if (offp < len || k0 >= ix.r) break;
             offp -= len;
