@@ -211,32 +211,24 @@ __global__ void k_sentinel_rows(Row* rows, uint64_t r, int compact) {
     }
 }
 
-// Second half of the compact rows (spx_layout.h, Row32): the row of the likeliest destination run D = LFrun and
-// the heads of the other destinations, copied next to the row that points to them.  One thread per run, after
-// k_build_rows / k_sentinel_rows (reads the first halves, writes the second: no race).  Hrun: heads by run index.
-__global__ void k_embed_rows(Row* rows, const uint8_t* Hrun, uint64_t r) {
+// Second pass over the compact rows (spx_layout.h, Row32).  k_heads_rows: every row gets the heads of the first
+// two runs a step from it can land in; k_embed_rows: then the finished row of run D = LFrun is copied next to the
+// row that points to it.  Two kernels: the second reads the q1 the first wrote.  Hrun: heads by run index.
+__global__ void k_heads_rows(Row* rows, const uint8_t* Hrun, uint64_t r) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (k >= r + ROW_PAD) return;
     Row32* r32 = reinterpret_cast<Row32*>(rows);
-    Row own;
-    own.q0 = r32[k].q0;
-    own.q1 = r32[k].q1;
-    const uint64_t D = crow_LFrun(own);
-    auto head = [&](uint64_t run) -> uint32_t { return run < r ? Hrun[run] : 0u; };
-    Row d;
-    d.q0 = r32[D < r + ROW_PAD ? D : r].q0;
-    d.q1 = r32[D < r + ROW_PAD ? D : r].q1 & ~0xffff0000ull;  // (h1 / h2 of row D may or may not be there yet)
-    const uint64_t DD = crow_LFrun(d);
-    const uint32_t dh[4] = {head(DD), head(DD + 1), head(DD + 2), head(DD + 3)};
-    Row32 out = r32[k];
-    out.q1 &= ~0xffff0000ull;
-    // an embedded row is only stood on when the walk lands in a real run: D >= r (the "pos == n" sentinel) keeps
-    // its zero head, which no character matches
-    row32_embed(out, d, head(D + 1), head(D + 2), dh);
-    if (D >= r) out.e0 &= ~(0xffull << 16);
-    r32[k].q1 = out.q1;
-    r32[k].e0 = out.e0;
-    r32[k].e1 = out.e1;
+    const uint64_t D = r32[k].q0 >> 32;
+    r32[k].q1 = crow_with_dheads(r32[k].q1, D < r ? Hrun[D] : 0u, D + 1 < r ? Hrun[D + 1] : 0u);
+}
+__global__ void k_embed_rows(Row* rows, uint64_t r) {
+    const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (k >= r + ROW_PAD) return;
+    Row32* r32 = reinterpret_cast<Row32*>(rows);
+    uint64_t D = r32[k].q0 >> 32;
+    if (D > r) D = r;  // (padding rows)
+    r32[k].e0 = r32[D].q0;
+    r32[k].e1 = r32[D].q1;
 }
 
 __global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* out) {
@@ -504,7 +496,10 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                               docs ? dirdocs_tmp.as<uint32_t>() : nullptr,
                                               ix->rundocs, err.as<unsigned long long>());
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, compact);
-    if (compact) k_embed_rows<<<nblocks(r + ROW_PAD), TPB, 0, st>>>(ix->rows, H.as<uint8_t>(), r);
+    if (compact) {
+        k_heads_rows<<<nblocks(r + ROW_PAD), TPB, 0, st>>>(ix->rows, H.as<uint8_t>(), r);
+        k_embed_rows<<<nblocks(r + ROW_PAD), TPB, 0, st>>>(ix->rows, r);
+    }
     SPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(T.p);
     T.p = nullptr;

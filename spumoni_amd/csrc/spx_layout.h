@@ -102,18 +102,18 @@ SPX_HD Row pack_row_compact(uint32_t H, uint32_t len, uint32_t LFrun, uint32_t L
     return r;
 }
 // A compact index stores its rows as Row32 (32 bytes, 32-byte aligned: one 128-byte line, two 16-byte lane
-// loads): the compact row of run k, the heads of the runs a step from k can land in, and -- embedded -- what
-// the walk needs to STAND on the likeliest of them, run D = LFrun, without fetching D's own row:
-//     q0: as above                       q1: H[8] | thr_ok << 8 | h1[8] << 16 | h2[8] << 24 | cums << 32
-//     e0: D.LFoff[16] | D.H[8] << 16 | D.thr_ok << 24 | D.LFrun[32] << 32
-//     e1: D.cums[32] | heads of runs D.LFrun, D.LFrun+1, D.LFrun+2, D.LFrun+3 [8 each] << 32
-// h1, h2 = heads of runs LFrun+1, LFrun+2 (0 = unknown / past the last run; a head is never 0 after the
-// terminator rewrite).  A match step from (k, off) whose destination is exactly (LFrun, LFoff + off) -- cum0 > off,
-// half of the match steps on the statistical bench index, more on a real BWT -- goes on from the embedded row
-// at once: two LF steps per gather.  And whichever run a step lands in, if its head is known and the next
-// character differs from it, the next step is a jump, which needs only (run, offset): the landing row is not
-// fetched at all (what the jump rows' Hs does for landings after a jump).  tools/layout_sim.py: row gathers per
-// character 0.91 -> 0.50 on match-heavy reads, 0.46 -> 0.25 on the bench mix.
+// loads): the compact row of run k -- with the heads of the first two runs a step from k can land in -- and,
+// embedded in the same format, the row of the likeliest destination, run D = LFrun:
+//     q0: len[16] | LFoff[16] << 16 | LFrun[32] << 32
+//     q1: H[8] | thr_ok << 8 | hd0[8] << 16 | hd1[8] << 24 | cums << 32      hd_i = head of run LFrun + i
+//     e0, e1: q0, q1 of run D (its own hd0 / hd1 included)
+// (hd = 0: past the last run; a head is never 0 after the terminator rewrite.)  A step from (k, off) whose
+// destination is exactly (LFrun, LFoff + off) -- cum0 > off: half of the match steps on the statistical bench
+// index, more on a real BWT -- goes on from the embedded row at once: two LF steps per gather.  And when the
+// head of the run a step lands in is known and the next character differs from it, the next step is a jump,
+// which needs only (run, offset): the landing row is not fetched at all (what the jump rows' Hs does for
+// landings after a jump).  tools/layout_sim.py: row gathers per character 0.91 -> 0.50 on match-heavy reads,
+// 0.46 -> 0.25 on the bench mix.
 struct alignas(32) Row32 {
     uint64_t q0, q1, e0, e1;
 };
@@ -123,16 +123,9 @@ SPX_HD uint32_t crow_LFrun(const Row& r) { return (uint32_t)(r.q0 >> 32); }
 SPX_HD uint32_t crow_H(const Row& r) { return (uint32_t)r.q1 & 0xff; }
 SPX_HD bool crow_thr_ok(const Row& r) { return (r.q1 >> 8) & 1; }
 SPX_HD uint32_t crow_cums(const Row& r) { return (uint32_t)(r.q1 >> 32); }
-// heads of the destination runs LFrun, LFrun+1, LFrun+2, (unknown) of a full Row32, a byte each
-SPX_HD uint32_t row32_dheads(const Row32& r) {
-    return ((uint32_t)(r.e0 >> 16) & 0xffu) | (((uint32_t)(r.q1 >> 16) & 0xffffu) << 8);
-}
-SPX_HD void row32_embed(Row32& r, const Row& d, uint32_t h1, uint32_t h2, const uint32_t dh[4]) {
-    r.q1 |= ((uint64_t)(h1 & 0xff) << 16) | ((uint64_t)(h2 & 0xff) << 24);
-    r.e0 = (uint64_t)crow_LFoff(d) | ((uint64_t)crow_H(d) << 16) | ((uint64_t)(crow_thr_ok(d) ? 1 : 0) << 24) |
-           ((uint64_t)crow_LFrun(d) << 32);
-    r.e1 = (uint64_t)crow_cums(d) | ((uint64_t)((dh[0] & 0xff) | ((dh[1] & 0xff) << 8) | ((dh[2] & 0xff) << 16) |
-                                                ((dh[3] & 0xff) << 24)) << 32);
+SPX_HD uint32_t crow_dheads(uint64_t q1) { return (uint32_t)(q1 >> 16) & 0xffffu; }  // hd0 | hd1 << 8
+SPX_HD uint64_t crow_with_dheads(uint64_t q1, uint32_t hd0, uint32_t hd1) {
+    return (q1 & ~0xffff0000ull) | ((uint64_t)(hd0 & 0xff) << 16) | ((uint64_t)(hd1 & 0xff) << 24);
 }
 
 struct alignas(32) JumpRow {

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp, tt);    \
             if (tt == 0 && emb_ok) {                                     \
                 stand = true;                                            \
-            } else if (tt < 4) {                                         \
+            } else if (tt < 2) {                                         \
                 Hland = (dheads >> (8 * tt)) & 0xffu;                    \
                 peek = Hland != 0;                                       \
             }                                                            \
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     e0 = g2;
                     e1 = g3;
                     emb_ok = true;
-                    dheads = ((uint32_t)(g2 >> 16) & 0xffu) | (((uint32_t)(g1 >> 16) & 0xffffu) << 8);
+                    dheads = crow_dheads(g1);
                 }
                 do_step = true;
             }
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                         e0 = ix.init_row.e0;
                         e1 = ix.init_row.e1;
                         emb_ok = true;
-                        dheads = row32_dheads(ix.init_row);
+                        dheads = crow_dheads(ix.init_row.q1);
                     }
                 }
                 {
@@ -832,12 +832,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     // the step ended in run LFrun, whose row travelled with the row the walk stood on
                     k = k0;
                     off = offp;
-                    H_k = (uint32_t)(e0 >> 16) & 0xffu;
-                    thr_ok_k = (e0 >> 24) & 1;
-                    LFoff_k = (offs_t)((uint32_t)e0 & 0xffffu);
+                    H_k = (uint32_t)e1 & 0xffu;
+                    thr_ok_k = (e1 >> 8) & 1;
+                    LFoff_k = (offs_t)((uint32_t)(e0 >> 16) & 0xffffu);
                     LFrun_k = (uint32_t)(e0 >> 32);
-                    room_k = (uint32_t)e1;
-                    dheads = (uint32_t)(e1 >> 32);
+                    room_k = (uint32_t)(e1 >> 32);
+                    dheads = crow_dheads(e1);
                     emb_ok = false;
                     ph = P_STEP;
                     again = true;
@@ -902,6 +902,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     atomicAdd(&b.counters->dir_loads, (unsigned long long)n_dir);
     if (n_err) atomicAdd(&b.counters->error, (unsigned long long)n_err);
 }
+
+#include "spx_walk_pml.inc"
 
 // ---------------------------------------------------------------------------
 // MS length extension: ms_t::matching_statistics second loop
@@ -1142,11 +1144,19 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         set_error("internal: PML walk without prepare_len_mask");
         return SPX_E_ARG;
     }
+    // the plain PML walk over compact rows has a body of its own (spx_walk_pml.inc); SPX_OLD_WALK=1 keeps the
+    // state machine for it too (A/B runs, and the tests that hold the two against each other)
+    static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
+    const bool fast = MODE == SPX_MODE_PML && !DOC && COMPACT && CHUNK == 0 && args.only_flagged == nullptr && !old_walk &&
+                      args.nreads < (1ull << 31);
     // resident blocks per CU and CU count are looked up once per index and kernel variant
-    const int slot = MODE * 2 + (DOC ? 1 : 0);
+    const int slot = fast ? 4 : MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
-        SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW, 0>, WALK_TPB, 0));
+        if (fast)
+            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_pml, WALK_TPB, 0));
+        else
+            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW, 0>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
     }
     if (ix->num_cus == 0) {
@@ -1195,7 +1205,10 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         grid = (items + lpw - 1) / lpw;
     }
     if (grid == 0) grid = 1;
-    k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+    if (fast)
+        k_walk_pml<<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+    else
+        k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
@@ -1578,8 +1591,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, 
     const uint64_t base = b.offs[rd], end = b.offs[rd + 1], m = end - base;
     if (m == 0) return;
     const uint64_t pair0 = ((base - b.offs[0]) >> 7) + rd;
-    const uint32_t nw = 2 * (uint32_t)((m + 127) >> 7);
-    if (pair0 + nw / 2 > b.len_mask_pairs) return;  // more characters than total_chars said: the walk reported it
+    const uint32_t nw = (uint32_t)((m + 63) >> 6);  // (k_walk_pml writes the words that hold characters, no more)
+    if (pair0 + (nw + 1) / 2 > b.len_mask_pairs) return;  // more characters than total_chars said: the walk reported it
     const uint64_t* const mw = b.len_mask + 2 * pair0;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);
     for (uint64_t G = (base >> 3) + j; G <= ((end - 1) >> 3); G += lpr) {
