@@ -149,7 +149,7 @@ struct spx_index {
     hipStream_t last_stream = nullptr;
     uint64_t device_bytes = 0;
     int waves_per_cu = 0; // 0 = default occupancy target
-    int occ_blocks[5] = {0, 0, 0, 0, 0};  // resident 256-thread blocks per CU, per kernel variant (4: k_walk_pml)
+    int occ_blocks[8] = {};  // resident 256-thread blocks per CU, per kernel variant (4..7: k_walk_fast)
     int num_cus = 0;
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
     int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read

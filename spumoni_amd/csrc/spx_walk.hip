@@ -52,8 +52,7 @@ enum : uint32_t {
     P_FATJ = 8,
     P_DONE = 9,
     P_START = 10,  // chunked walk, pass 2: the end state of the chunk above
-    P_CKPT = 11,   // chunked walk, pass 2: the speculative walk's state at a checkpoint
-    P_STEP = 12    // standing on a row already (the embedded one): nothing to fetch, look at the next character
+    P_CKPT = 11    // chunked walk, pass 2: the speculative walk's state at a checkpoint
 };
 
 constexpr int WALK_TPB = 256;
@@ -92,7 +91,7 @@ __device__ __forceinline__ void lf_target(uint32_t LFrun, OFFS LFoff, uint32_t r
 // unless it lies further than that.
 template <class OFFS>
 __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t cums, OFFS off, uint32_t& k0,
-                                            OFFS& offp, uint32_t& t_out) {
+                                            OFFS& offp) {
     const uint32_t o = off < 126 ? (uint32_t)off : 126u;
     // byte i gets its top bit iff cum_i <= o (no borrows: every byte of the minuend is >= 128)
     const uint32_t flags = (((o * 0x01010101u) | 0x80808080u) - cums) & 0x80808080u;
@@ -100,9 +99,6 @@ __device__ __forceinline__ void lf_target_c(uint32_t LFrun, OFFS LFoff, uint32_t
     const uint32_t prev = (cums >> (8 * ((t + 3) & 3))) & 0x7fu;  // cum_{t-1} (unused when t == 0)
     k0 = LFrun + t;
     offp = t ? off - prev : LFoff + off;
-    // the landing is exact -- the step ends in run LFrun + t, no row to skip -- when the bounding cum is a true
-    // value: t < 4 and off below the saturation mark; 4 = "not known"
-    t_out = (t < 4 && off <= 126) ? t : 4u;
 }
 
 // Output staging.  A lane's stores go to its own read: 64 lanes, 64 different cache lines per store
@@ -256,12 +252,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     // jump bookkeeping
     uint32_t c = 0, jdir = 0, qbeg = 0, qend = 0, aux_take = 0, Hland = 0;
     bool quirk = false, peek = false;
-    // compact rows (Row32, spx_layout.h): the embedded row of the likeliest destination run, and the heads of
-    // the runs a step from here can land in (a byte each, 0 = not known)
-    uint64_t e0 = 0, e1 = 0;
-    bool emb_ok = false, stand = false;
-    uint32_t dheads = 0, tt = 4;
-    constexpr uint32_t ROW_STRIDE = COMPACT ? sizeof(Row32) : sizeof(Row);
     // character window: the 32 bytes of the read starting at byte offset wbase of seqs, kept in LDS
     // as [dword j of the window][thread] (conflict-free) -- eight registers and a select chain less
     // than holding it in VGPRs (90 -> 72 registers, DNA walks +7 %)
@@ -317,21 +307,12 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         rd += nlanes;                             \
         ph = rd < nitems ? P_READ : P_DONE;       \
     } while (0)
-// LF of (k, off) and, for compact rows, what is known about the landing before any gather: the walk goes on from
-// the embedded row when the step ends exactly in run LFrun (stand), or knows the head of the run it ends in (peek)
 #define LF_TARGET()                                                      \
     do {                                                                 \
-        if (COMPACT) {                                                   \
-            lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp, tt);    \
-            if (tt == 0 && emb_ok) {                                     \
-                stand = true;                                            \
-            } else if (tt < 2) {                                         \
-                Hland = (dheads >> (8 * tt)) & 0xffu;                    \
-                peek = Hland != 0;                                       \
-            }                                                            \
-        } else {                                                         \
+        if (COMPACT)                                                     \
+            lf_target_c(LFrun_k, LFoff_k, room_k, off, k0, offp);        \
+        else                                                             \
             lf_target(LFrun_k, LFoff_k, room_k, off, k0, offp);          \
-        }                                                                \
     } while (0)
 
     while (ph != P_DONE) {
@@ -339,7 +320,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         const char* p0;
         uint64_t fidx = 0;  // fat-table slot (P_FAT only)
         if (ph == P_LAND) {
-            p0 = rows_b + (uint64_t)k0 * ROW_STRIDE;
+            // (a compact index keeps its rows 32 bytes apart, spx_layout.h Row32: this kernel reads the row itself,
+            // k_walk_fast also what is embedded next to it)
+            p0 = rows_b + (uint64_t)k0 * (COMPACT ? sizeof(Row32) : sizeof(Row));
         } else if (ph == P_FAT) {
             fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
             p0 = fat_b + fidx * ix.fat_stride;
@@ -364,8 +347,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
         } else {
             p0 = rows_b;
         }
-        const bool wide = (COMPACT && ph == P_LAND) | (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS) |
-                          (CHUNK == 2 && (ph == P_START || ph == P_CKPT));
+        const bool wide = (ph == P_DIR) | (ph == P_QS) | (ph == P_CHARS) | (CHUNK == 2 && (ph == P_START || ph == P_CKPT));
         const V16 ga = *reinterpret_cast<const V16*>(p0);
         V16 gb{0, 0, 0, 0};
         if (wide) gb = *reinterpret_cast<const V16*>(p0 + 16);
@@ -406,16 +388,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 k = k0;
                 off = offp;
                 STAND_ON(ra);
-                if (COMPACT) {
-                    e0 = g2;
-                    e1 = g3;
-                    emb_ok = true;
-                    dheads = crow_dheads(g1);
-                }
                 do_step = true;
             }
-        } else if (ph == P_STEP) {
-            do_step = true;
         } else if (ph == P_FAT) {
             n_dir++;
             const uint32_t hq = (uint32_t)g0;
@@ -540,12 +514,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                     ir.q0 = ix.init_row.q0;
                     ir.q1 = ix.init_row.q1;
                     STAND_ON(ir);
-                    if (COMPACT) {
-                        e0 = ix.init_row.e0;
-                        e1 = ix.init_row.e1;
-                        emb_ok = true;
-                        dheads = crow_dheads(ix.init_row.q1);
-                    }
                 }
                 {
                     const uint64_t end4 = (base + m + 3) & ~3ull;  // window ends past the last character
@@ -643,12 +611,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             }
         }
 
-        // Step and emit, up to twice per gather: a step that ends exactly in the run whose row came embedded in
-        // the row the walk stood on goes on from there (spx_layout.h, Row32) -- two LF steps for one gather.
-        bool again;
-#pragma clang loop unroll(disable)
-        do {
-        again = false;
         if (do_step) {
             // next character: auto c = pattern[m - i - 1]   (:247)
             const uint64_t g = base + x - 1;
@@ -828,20 +790,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 NEXT_ITEM();
             } else {
                 ph = P_LAND;
-                if (COMPACT && stand) {
-                    // the step ended in run LFrun, whose row travelled with the row the walk stood on
-                    k = k0;
-                    off = offp;
-                    H_k = (uint32_t)e1 & 0xffu;
-                    thr_ok_k = (e1 >> 8) & 1;
-                    LFoff_k = (offs_t)((uint32_t)(e0 >> 16) & 0xffffu);
-                    LFrun_k = (uint32_t)(e0 >> 32);
-                    room_k = (uint32_t)(e1 >> 32);
-                    dheads = crow_dheads(e1);
-                    emb_ok = false;
-                    ph = P_STEP;
-                    again = true;
-                } else if (peek) {
+                if (peek) {
                     // The jump row told us the head of the run we land in.  If the next character
                     // is present in the index and differs from it, the next step is a jump again
                     // -- from (k0, offp), which is all a jump needs -- and the landing row is
@@ -855,7 +804,6 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                             k = k0;
                             off = offp;
                             H_k = Hland;
-                            emb_ok = false;
                             c = cn;
                             quirk = false;
                             qbeg = li.qbeg;
@@ -868,22 +816,17 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 }
             }
             peek = false;
-            stand = false;
             if (CHUNK && x != 0 && ((base + x) & ((1u << CKPT_SHIFT) - 1)) == 0) {
                 // checkpoint: the state before character base + x - 1
                 if (CHUNK == 1) {
                     ch_ckpt[(base + x) >> CKPT_SHIFT] =
                         WalkState{k0, length, (offp == OFF_LAST) ? OFF_END : (uint64_t)offp, sample, doc, seen};
                 } else {
-                    ph_after = ph;  // (P_STEP: the walk goes on from the embedded row after the comparison)
+                    ph_after = ph;
                     ph = P_CKPT;
-                    again = false;
                 }
             }
         }
-        do_step = again;
-        do_emit = false;
-        } while (COMPACT && again);
         // One flat loop, one back edge.  Hiding the phase from the optimiser here keeps it from
         // threading the "read finished" path into a back edge of its own and splitting the loop
         // into an outer per-read and an inner per-character loop -- in which every lane waits at
@@ -903,7 +846,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     if (n_err) atomicAdd(&b.counters->error, (unsigned long long)n_err);
 }
 
-#include "spx_walk_pml.inc"
+#include "spx_walk_fast.inc"
 
 // ---------------------------------------------------------------------------
 // MS length extension: ms_t::matching_statistics second loop
@@ -1144,17 +1087,16 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         set_error("internal: PML walk without prepare_len_mask");
         return SPX_E_ARG;
     }
-    // the plain PML walk over compact rows has a body of its own (spx_walk_pml.inc); SPX_OLD_WALK=1 keeps the
-    // state machine for it too (A/B runs, and the tests that hold the two against each other)
+    // the plain walk over compact rows has a body of its own (spx_walk_fast.inc); SPX_OLD_WALK=1 keeps the state
+    // machine for it too (A/B runs, and the tests that hold the two against each other)
     static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
-    const bool fast = MODE == SPX_MODE_PML && !DOC && COMPACT && CHUNK == 0 && args.only_flagged == nullptr && !old_walk &&
-                      args.nreads < (1ull << 31);
+    const bool fast = COMPACT && CHUNK == 0 && args.only_flagged == nullptr && !old_walk && args.nreads < (1ull << 31);
     // resident blocks per CU and CU count are looked up once per index and kernel variant
-    const int slot = fast ? 4 : MODE * 2 + (DOC ? 1 : 0);
+    const int slot = (fast ? 4 : 0) + MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
         if (fast)
-            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_pml, WALK_TPB, 0));
+            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_fast<MODE, DOC, NARROW>, WALK_TPB, 0));
         else
             SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW, 0>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
@@ -1206,7 +1148,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     }
     if (grid == 0) grid = 1;
     if (fast)
-        k_walk_pml<<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+        k_walk_fast<MODE, DOC, NARROW><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     else
         k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
@@ -1591,7 +1533,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, 
     const uint64_t base = b.offs[rd], end = b.offs[rd + 1], m = end - base;
     if (m == 0) return;
     const uint64_t pair0 = ((base - b.offs[0]) >> 7) + rd;
-    const uint32_t nw = (uint32_t)((m + 63) >> 6);  // (k_walk_pml writes the words that hold characters, no more)
+    const uint32_t nw = (uint32_t)((m + 63) >> 6);  // (k_walk_fast writes the words that hold characters, no more)
     if (pair0 + (nw + 1) / 2 > b.len_mask_pairs) return;  // more characters than total_chars said: the walk reported it
     const uint64_t* const mw = b.len_mask + 2 * pair0;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);

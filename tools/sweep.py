@@ -46,7 +46,7 @@ if which in ("all", "dna"):
     del raw, seqs, offs
 if which in ("all", "ms"):
     raw = synth.statistical_rlbwt(1 << 27, 253, 8.0, seed=5, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
-    seqs, offs = synth.simulate_reads(raw, 5_000_000, 55, seed=15)
+    seqs, offs = synth.simulate_reads(raw, 5_000_000, 55, seed=15, warmup=int(os.environ.get("SWEEP_WARMUP", "4")))
     run("C4 MS + doc sigma=253 m=55", raw, seqs, offs, mode=capi.SPX_MODE_MS, docs=True)
     run("C4-shaped PML + doc", raw, seqs, offs, docs=True)
     del raw, seqs, offs
