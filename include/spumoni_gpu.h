@@ -125,6 +125,24 @@ int spx_index_rebuild_text(spx_index *ix);
  * only *n_text is filled.  where: 0 host, 1 device.                                              */
 int spx_index_copy_text(spx_index *ix, uint8_t *out, uint64_t capacity, int where, uint64_t *n_text);
 
+/* ---- the vectors as text --------------------------------------------------
+ * The reference writes every vector as text: under a ">id" line one line of "<value> " per character
+ * (compute_ms_pml.cpp:1001-1010, 1182-1205; std::ostream_iterator<size_t>(file, " ")).  At GPU speed the
+ * digits are the job, and the values are in HBM: spx_query_text_begin runs [digestion (digest_kind 0: none) +]
+ * the query and formats the requested streams (SPX_TEXT_*: .pseudo_lengths / .lengths, .pointers,
+ * .doc_numbers) on the device; read q's record is  gap[q] free bytes  +  its values line  +  '\n'  (gap NULL:
+ * none) -- the caller drops ">id\n" into the gap, ids never travel.  out_bytes[i] = size of stream i (0: not
+ * asked for).  spx_query_text_fetch then copies the streams (and, when line_start[i] is given, the nreads + 1
+ * record offsets) into the caller's buffers (page-locked ones copy at DMA speed) -- the next call on the
+ * same index after a successful begin, from the same thread.                                             */
+#define SPX_TEXT_LENGTHS 1u
+#define SPX_TEXT_POINTERS 2u
+#define SPX_TEXT_DOCS 4u
+int spx_query_text_begin(spx_index *ix, int mode, int digest_kind, uint32_t k, uint32_t w, const uint8_t *seqs,
+                         const uint64_t *offsets, uint64_t nreads, const uint32_t *gap, uint32_t streams,
+                         spx_class *out_class, uint64_t bin_width, uint64_t max_value_thr, uint64_t out_bytes[3]);
+int spx_query_text_fetch(spx_index *ix, char *text[3], uint64_t *line_start[3]);
+
 /* ---- flat-layout cache and replication -------------------------------------
  * pml_t / ms_t deserialise their index on every run (compute_ms_pml.cpp:700-721,
  * 755-786, the timed "loading the index" step).  Here the raw run files are
@@ -139,6 +157,12 @@ const char *spx_version(void);
 int spx_index_save(spx_index *ix, const char *path);
 spx_index *spx_index_load_flat(const char *path, int device);
 spx_index *spx_index_clone(spx_index *src, int device);
+/* What the index was built from, as the caller names it (at most 127 characters; the host harness: names,
+ * sizes and modification times of <ref>.bwt.heads / .bwt.len / .thr_pos / ...).  Saved with the cache and
+ * handed back by an index loaded from it: pml_t / ms_t always deserialise the CURRENT files
+ * (compute_ms_pml.cpp:700-721), so a cache whose tag differs from the files' is stale and must not be used. */
+int spx_index_set_source_tag(spx_index *ix, const char *tag);
+const char *spx_index_source_tag(const spx_index *ix);
 /* one-line JSON description of the layout (sizes, fat-table density, version) */
 int spx_index_describe(const spx_index *ix, char *buf, size_t cap);
 

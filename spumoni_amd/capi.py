@@ -50,7 +50,12 @@ EXPORTS = [
     "spx_last_chunk_stats",
     "spx_index_rebuild_text",
     "spx_index_copy_text",
+    "spx_index_set_source_tag",
+    "spx_index_source_tag",
+    "spx_query_text_begin",
+    "spx_query_text_fetch",
 ]
+SPX_TEXT_LENGTHS, SPX_TEXT_POINTERS, SPX_TEXT_DOCS = 1, 2, 4
 SPX_TEXT_UNCHECKED = 2
 
 SPX_DIGEST_PROMOTED, SPX_DIGEST_DNA = 1, 2
@@ -110,6 +115,11 @@ def lib() -> C.CDLL:
         L.spx_index_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.spx_index_device_bytes.argtypes = [vp, C.POINTER(u64)]
         L.spx_index_set_text.argtypes = [vp, vp, u64, i32]
+        L.spx_index_set_source_tag.argtypes = [vp, C.c_char_p]
+        L.spx_index_source_tag.restype = C.c_char_p
+        L.spx_index_source_tag.argtypes = [vp]
+        L.spx_query_text_begin.argtypes = [vp, i32, i32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, C.c_uint32, vp, u64, u64, vp]
+        L.spx_query_text_fetch.argtypes = [vp, vp, vp]
         L.spx_query_batch.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
         L.spx_query_batch_device.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
         L.spx_query_batch16.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
@@ -219,6 +229,13 @@ class Index:
     def save(self, path: str) -> None:
         _check(lib().spx_index_save(self._h, path.encode()))
 
+    def set_source_tag(self, tag: str) -> None:
+        """The caller's fingerprint of what the index was built from; travels with save() / load_flat() / clone()."""
+        _check(lib().spx_index_set_source_tag(self._h, tag.encode()))
+
+    def source_tag(self) -> str:
+        return lib().spx_index_source_tag(self._h).decode()
+
     def clone(self, device: int) -> "Index":
         """A copy of this index on `device` (device-to-device, no re-flattening)."""
         h = lib().spx_index_clone(self._h, device)
@@ -297,6 +314,27 @@ class Index:
         if cls_ is not None:
             out["class"] = cls_[:nreads]
         return out
+
+    def query_text(self, mode, seqs, offs, gap=None, streams=SPX_TEXT_LENGTHS, digest=(0, 0, 0), classify=None):
+        """The vectors as the text of the output files (spx_query_text_begin / _fetch).  Returns
+        {"text": [bytes | None] * 3, "line_start": [uint64 array | None] * 3, "class": ...}; stream i = lengths,
+        pointers, document ids."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        nreads = offs.size - 1
+        g = None if gap is None else np.ascontiguousarray(gap, dtype=np.uint32)
+        cls_ = np.zeros(max(nreads, 1), dtype=CLASS_DTYPE) if classify else None
+        bw, thr = classify if classify else (0, 0)
+        nbytes = (C.c_uint64 * 3)()
+        _check(lib().spx_query_text_begin(self._h, mode, digest[0], digest[1], digest[2], _np_ptr(seqs), _np_ptr(offs), nreads,
+                                          _np_ptr(g), streams, _np_ptr(cls_), bw, thr, C.cast(nbytes, C.c_void_p)))
+        bufs = [np.zeros(int(nbytes[i]) + 1, dtype=np.uint8) if nbytes[i] else None for i in range(3)]
+        starts = [np.zeros(nreads + 1, dtype=np.uint64) if nbytes[i] else None for i in range(3)]
+        tp = (C.c_void_p * 3)(*[_np_ptr(b) for b in bufs])
+        lp = (C.c_void_p * 3)(*[_np_ptr(b) for b in starts])
+        _check(lib().spx_query_text_fetch(self._h, C.cast(tp, C.c_void_p), C.cast(lp, C.c_void_p)))
+        return {"text": [None if b is None else b[: int(nbytes[i])].tobytes() for i, b in enumerate(bufs)],
+                "line_start": starts, "class": None if cls_ is None else cls_[:nreads]}
 
     # -- queries, device buffers (torch tensors on self.device) -------------
     def query_device(self, mode, d_seqs, d_offs, total_chars, d_lengths=None, d_pointers=None, d_docs=None,

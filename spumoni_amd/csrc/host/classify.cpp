@@ -1,5 +1,7 @@
 #include "classify.hpp"
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -34,6 +36,38 @@ static bool file_exists(const std::string& p) {
     return f.good();
 }
 
+// What the flat index is built from, as a short string: size and modification time of every file `run` would read
+// for this mode (raw run files and / or the serialised index, the document array, the text), folded into one
+// 64-bit FNV-1a value.  pml_t / ms_t always deserialise the CURRENT files (compute_ms_pml.cpp:700-721, 755-786):
+// a cache whose tag differs was written for other files and is not used.
+static std::string source_fingerprint(const RunOptions& o) {
+    std::vector<std::string> names = {".bwt.heads", ".bwt.len", ".thr_pos", o.ms ? ".thrbv.ms" : ".thrbv.spumoni"};
+    if (o.ms) {
+        names.push_back(".ssa");
+        names.push_back(".esa");
+    }
+    if (o.use_doc) names.push_back(".doc");
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 1099511628211ull;
+    };
+    int found = 0;
+    auto add = [&](const std::string& path, const std::string& label) {
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0) return;
+        ++found;
+        const uint64_t v[3] = {(uint64_t)st.st_size, (uint64_t)st.st_mtim.tv_sec, (uint64_t)st.st_mtim.tv_nsec};
+        mix(label.data(), label.size());
+        mix(v, sizeof v);
+    };
+    for (const std::string& nm : names) add(o.ref_file + nm, nm);
+    if (o.ms && !o.text_file.empty()) add(o.text_file, "text");
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "%s%s:%d files:%016llx", o.ms ? "ms" : "pml", o.use_doc ? "+doc" : "", found,
+                  (unsigned long long)h);
+    return buf;
+}
+
 // One flatten (or one read of the flat-layout cache), then device-to-device copies: the reference
 // deserialises its index once per run (pml_t::pml_t / ms_t::ms_t, compute_ms_pml.cpp:700-721, 755-786);
 // N devices cost one load plus N-1 peer copies, not N loads.
@@ -46,13 +80,21 @@ void IndexSet::load(const RunOptions& o) {
     const std::string cache = o.ref_file + (o.ms ? ".ms" : ".pml") + (o.use_doc ? ".doc" : "") + ".spx";
     const int dev0 = o.devices.empty() ? 0 : o.devices[0];
     spx_index* first = nullptr;
+    const std::string tag = source_fingerprint(o);
     if (policy != "off" && file_exists(cache)) {
         first = spx_index_load_flat(cache.c_str(), dev0);
-        if (!first)
+        if (!first) {
             std::fprintf(stderr, "\n[spumoni-gpu] %s not used (%s): flattening the index files instead\n", cache.c_str(),
                          spx_last_error());
-        else
+        } else if (tag != spx_index_source_tag(first)) {
+            // written for other index files (the index was rebuilt under the same prefix, or another text was given)
+            std::fprintf(stderr, "\n[spumoni-gpu] %s is stale (it was written for '%s', the index files are now '%s'): "
+                                 "flattening the index files instead\n", cache.c_str(), spx_index_source_tag(first), tag.c_str());
+            spx_index_free(first);
+            first = nullptr;
+        } else {
             from_cache = true;
+        }
     }
     if (!first) {
         RawIndex raw;
@@ -84,6 +126,7 @@ void IndexSet::load(const RunOptions& o) {
         } else if (o.ms) {
             if (spx_index_rebuild_text(first) != SPX_OK) fatal_error("%s", spx_last_error());
         }
+        (void)spx_index_set_source_tag(first, tag.c_str());
         if (policy == "write" && spx_index_save(first, cache.c_str()) != SPX_OK)
             std::fprintf(stderr, "\n[spumoni-gpu] could not write %s: %s\n", cache.c_str(), spx_last_error());
     }
@@ -248,6 +291,14 @@ struct Results {
     // results of read q are entries [beg[q], end[q]) of the arrays above: the read's own
     // offsets, or -- with -m / -a -- the offsets of the digested read
     std::vector<uint64_t> beg, end;
+    // device_text: the vectors came back as the text of the output files (spx_query_text_begin / _fetch): stream i
+    // (0 lengths, 1 pointers, 2 document ids) holds, for read q, gap bytes for its ">id\n" line and its values line
+    // at [line_start[i][q], line_start[i][q + 1]); beg / end then only say whether a read has values at all
+    bool device_text = false;
+    uint32_t streams = 0;  // SPX_TEXT_* present in text[]
+    PinnedBuf<char> text[3];
+    PinnedBuf<uint64_t> line_start[3];
+    std::vector<uint32_t> gap;
 };
 
 // One super-batch on one device (the worker thread of that device calls this): the batch form of the
@@ -276,6 +327,42 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     res.beg.resize(nreads);
     res.end.resize(nreads);
     int rc;
+    // SPUMONI_HOST_FORMAT=1: values over PCIe, digits on the host cores (the round-2 path; A/B runs and tests)
+    static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
+    const bool no_len_text = o.report_only && !o.ms && o.write_report;
+    const uint32_t streams = (no_len_text ? 0u : SPX_TEXT_LENGTHS) | (o.ms ? SPX_TEXT_POINTERS : 0u) | (o.use_doc ? SPX_TEXT_DOCS : 0u);
+    res.device_text = !host_format && streams != 0;
+    res.streams = res.device_text ? streams : 0;
+    if (res.device_text) {
+        // the output files' text is written on the device (compute_ms_pml.cpp:1001-1010, 1182-1205): what comes back
+        // over PCIe is the files' new tail, with room for every ">id\n"
+        res.gap.resize(nreads);
+        for (size_t q = 0; q < nreads; ++q) res.gap[q] = (uint32_t)sb.ids[q].size() + 2;
+        uint64_t bytes[3] = {0, 0, 0};
+        rc = spx_query_text_begin(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, digest ? kind : 0, (uint32_t)o.k, (uint32_t)o.w,
+                                  sb.seqs.data(), sb.offs.data(), nreads, res.gap.data(), streams,
+                                  o.write_report ? res.cls.data() : nullptr, o.bin_size, max_value_thr, bytes);
+        if (rc != SPX_OK) fatal_error("%s", spx_last_error());
+        char* tp[3] = {nullptr, nullptr, nullptr};
+        uint64_t* lp[3] = {nullptr, nullptr, nullptr};
+        int first = -1;
+        for (int i = 0; i < 3; ++i) {
+            if (!(streams & (1u << i))) continue;
+            if (first < 0) first = i;
+            res.text[i].resize_uninit(bytes[i] + 1);
+            res.line_start[i].resize_uninit(nreads + 1);
+            tp[i] = res.text[i].data();
+            lp[i] = res.line_start[i].data();
+        }
+        rc = spx_query_text_fetch(ix, tp, lp);
+        if (rc != SPX_OK) fatal_error("%s", spx_last_error());
+        const uint64_t* ls = res.line_start[first].data();
+        for (size_t q = 0; q < nreads; ++q) {  // (a read without values: its record is the header and a newline)
+            res.beg[q] = 0;
+            res.end[q] = ls[q + 1] - ls[q] - res.gap[q] - 1;
+        }
+        return;
+    }
     if (!digest) {
         // SPUMONI_REPORT_ONLY (PML): the per-character values are neither written nor copied back
         const bool no_len = o.report_only && !o.ms && o.write_report;
@@ -412,10 +499,35 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
     size_t formatted = 0;
     bool placed = false;
     auto lo_of = [&](size_t t) { return nreads * t / nt; };
+    OutFile* const files[3] = {&out.lengths, &out.pointers, &out.docs};
     auto work = [&](size_t t) {
         TextChunk& c = chunks[t];
         const auto tf0 = std::chrono::steady_clock::now();
-        format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
+        if (res.device_text) {
+            // the values lines are there already: drop the ">id\n" lines into their gaps, write the thread's stretch of
+            // every stream at its place behind the file's end, and format the report lines
+            const size_t lo = lo_of(t), hi = lo_of(t + 1);
+            for (int i = 0; i < 3; ++i) {
+                if (!(res.streams & (1u << i)) || !files[i]->is_open()) continue;
+                char* base = const_cast<char*>(res.text[i].data());
+                const uint64_t* ls = res.line_start[i].data();
+                for (size_t q = lo; q < hi; ++q) {
+                    char* p = base + ls[q];
+                    const std::string_view id = sb.ids[q];
+                    *p++ = '>';
+                    std::memcpy(p, id.data(), id.size());
+                    p[id.size()] = '\n';
+                }
+                if (hi > lo) files[i]->write_at(base + ls[lo], ls[hi] - ls[lo], files[i]->end + ls[lo]);
+            }
+            RunOptions ro = o;  // only the report is left to format
+            ro.use_doc = false;
+            ro.ms = false;
+            ro.report_only = true;
+            format_range(ro, sb, res, lo, hi, c);
+        } else {
+            format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
+        }
         if (t == 0) g_format_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
         {
             std::unique_lock<std::mutex> g(mu);
@@ -436,6 +548,10 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
                 cv.wait(g, [&] { return placed; });
             }
         }
+        if (res.device_text) {
+            if (o.write_report && !c.report.empty()) out.report.write_at(c.report.data(), c.report.size(), at_r[t]);
+            return;
+        }
         if (c.tl.len) out.lengths.write_at(c.tl.buf.data(), c.tl.len, at_l[t]);
         if (o.ms && c.tp.len) out.pointers.write_at(c.tp.buf.data(), c.tp.len, at_p[t]);
         if (o.use_doc && c.td.len) out.docs.write_at(c.td.buf.data(), c.td.len, at_d[t]);
@@ -445,6 +561,12 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
     for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    if (res.device_text) {
+        for (int i = 0; i < 3; ++i)
+            if ((res.streams & (1u << i)) && files[i]->is_open()) files[i]->end += res.line_start[i][nreads];
+        out.report.end = at_r[nt];
+        return;
+    }
     out.lengths.end = at_l[nt];
     out.pointers.end = at_p[nt];
     out.docs.end = at_d[nt];

@@ -1,3 +1,4 @@
+#include <sys/stat.h>
 // spx_api.hip -- the C-ABI of libspumoni_gpu.so (include/spumoni_gpu.h).
 // No CPU fallback exists anywhere in this library: without a gfx950 device every
 // entry point that needs one returns SPX_E_NODEVICE.
@@ -301,20 +302,33 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
     if (!unchecked && ix->has_samples) {
         // every run's first BWT character is the text character in front of its suffix:
         // text[samples_start[k]] == head of run k, for all r runs (one pass over the samples)
-        unsigned long long* d_bad = nullptr;
-        SPX_HIP(hipMalloc((void**)&d_bad, 8));
-        SPX_HIP(hipMemset(d_bad, 0, 8));
-        int rc = launch_text_check(ix, d_bad, nullptr);
-        unsigned long long bad = 0;
-        if (rc == SPX_OK && hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SPX_E_HIP;
-        (void)hipFree(d_bad);
-        if (rc != SPX_OK) return rc;
-        if (bad) {
+        // (whatever fails from here on, an UNCHECKED text must not stay bound to the index)
+        auto drop_text = [&] {
             (void)hipFree(ix->text);
             ix->text = nullptr;
             ix->n_text = 0;
             ix->arr_bytes[A_TEXT] = 0;
             bind_view(ix);
+        };
+        unsigned long long* d_bad = nullptr;
+        int rc = SPX_OK;
+        if (hipMalloc((void**)&d_bad, 8) != hipSuccess || hipMemset(d_bad, 0, 8) != hipSuccess) {
+            set_error("hipMalloc / hipMemset failed while checking the text");
+            rc = SPX_E_HIP;
+        }
+        if (rc == SPX_OK) rc = launch_text_check(ix, d_bad, nullptr);
+        unsigned long long bad = 0;
+        if (rc == SPX_OK && hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("hipMemcpy failed while checking the text");
+            rc = SPX_E_HIP;
+        }
+        if (d_bad) (void)hipFree(d_bad);
+        if (rc != SPX_OK) {
+            drop_text();
+            return rc;
+        }
+        if (bad) {
+            drop_text();
             set_error("text disagrees with the index at %llu of %llu runs (text[samples_start[k]] must be the head "
                       "of run k): not the text this index was built from", bad, (unsigned long long)ix->r);
             return SPX_E_FORMAT;
@@ -322,6 +336,21 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
     }
     return SPX_OK;
 }
+
+// A caller's fingerprint of what the index was built from (the host harness: names, sizes and modification times of
+// the index files): saved with the flat-layout cache and handed back after spx_index_load_flat, so that a cache left
+// over from an index that has since been rebuilt under the same prefix is recognised and not used.
+int spx_index_set_source_tag(spx_index* ix, const char* tag) {
+    if (!ix || !tag) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    snprintf(ix->source_tag, sizeof ix->source_tag, "%s", tag);
+    return SPX_OK;
+}
+
+const char* spx_index_source_tag(const spx_index* ix) { return ix ? ix->source_tag : ""; }
 
 int spx_index_rebuild_text(spx_index* ix) {
     if (!ix) {
@@ -612,14 +641,14 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     a.narrow = narrow ? 1 : 0;
     if ((rc = prepare_len_mask(ix, mode, a)) != SPX_OK) return rc;
     SPX_HIP(hipEventRecord(ix->ev0, st));
-    bool chunked = false;
+    bool chunked = false, wrote = false;
     if (nreads > 0) {
         if ((rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
-        if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st)) != SPX_OK) return rc;
+        if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st, &wrote)) != SPX_OK) return rc;
     }
     SPX_HIP(hipEventRecord(ix->ev1, st));
-    // PML: the plain walk left one bit per character; the lengths are written from them here
-    if (nreads > 0 && !chunked && (rc = launch_len_expand(ix, a, st)) != SPX_OK) return rc;
+    // PML, state-machine walk: it left one bit per character; the lengths are written from them here
+    if (nreads > 0 && !chunked && !wrote && (rc = launch_len_expand(ix, a, st)) != SPX_OK) return rc;
     if (mode == SPX_MODE_MS && d_out_lengths && nreads > 0) {
         a.out_class = d_out_class;
         rc = launch_ms_extend(ix, a, st);
@@ -744,10 +773,10 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         args.narrow = width == 2 ? 1 : 0;
         if ((rc = prepare_len_mask(ix, mode, args)) != SPX_OK) return rc;
         {  // a chunk of few, long reads is cut further and walked chunk-wise (spx_walk.hip)
-            bool chunked = false;
+            bool chunked = false, wrote = false;
             if ((rc = launch_walk_chunked(ix, mode, args, b - a, s_k, &chunked)) != SPX_OK) return rc;
-            if (!chunked && ((rc = launch_walk(ix, mode, args, b - a, s_k)) != SPX_OK ||
-                             (rc = launch_len_expand(ix, args, s_k)) != SPX_OK))
+            if (!chunked && ((rc = launch_walk(ix, mode, args, b - a, s_k, &wrote)) != SPX_OK ||
+                             (!wrote && (rc = launch_len_expand(ix, args, s_k)) != SPX_OK)))
                 return rc;
         }
         if (mode == SPX_MODE_MS && dlen) {
@@ -868,6 +897,131 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
+// The vectors as the text the reference writes (compute_ms_pml.cpp:1001-1010, 1182-1205), produced on the device
+// (spx_text.hip): spx_query_text_begin runs [digestion +] the walk [+ the MS extension] and formats; the sizes of
+// the streams come back, the caller sizes its (page-locked) buffers, spx_query_text_fetch copies the text.
+// ---------------------------------------------------------------------------------------------
+int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, uint32_t w, const uint8_t* seqs,
+                         const uint64_t* offsets, uint64_t nreads, const uint32_t* gap, uint32_t streams,
+                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr, uint64_t out_bytes[3]) {
+    if (!ix || !seqs || !offsets || !out_bytes) {
+        set_error("index, seqs, offsets and out_bytes must be non-null");
+        return SPX_E_ARG;
+    }
+    const bool want_len = streams & SPX_TEXT_LENGTHS, want_ptr = streams & SPX_TEXT_POINTERS, want_doc = streams & SPX_TEXT_DOCS;
+    // (check_query looks at which outputs are asked for, not at the pointers' targets)
+    int rc = check_query(ix, mode, seqs, offsets, (want_len || (mode == SPX_MODE_MS && out_class)) ? (uint32_t*)1 : nullptr, (mode == SPX_MODE_MS) ? (uint64_t*)1 : nullptr,
+                         want_doc ? (uint32_t*)1 : nullptr, out_class, bin_width);
+    if (rc != SPX_OK) return rc;
+    if (want_ptr && mode != SPX_MODE_MS) {
+        set_error("the pointers stream is only produced in MS mode");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> hg(ix->host_mu);
+    ix->text_ready = false;
+    SPX_HIP(hipSetDevice(ix->device));
+    const uint64_t total_in = nreads ? offsets[nreads] : 0;
+    void *dseq = nullptr, *doff = nullptr, *dgap = nullptr;
+    const uint64_t padded = ((total_in + 3) / 4) * 4 + 32;
+    if ((rc = ensure_scratch(ix, digest_kind ? 6 : 0, padded, &dseq)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 8, (nreads + 1) * 4, &dgap)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpy(dseq, seqs, total_in, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemset((char*)dseq + total_in, 0, padded - total_in));
+    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    if (gap) SPX_HIP(hipMemcpy(dgap, gap, nreads * 4, hipMemcpyHostToDevice));
+    const uint8_t* wseq = (const uint8_t*)dseq;
+    const uint64_t* woff = (const uint64_t*)doff;
+    uint64_t total = total_in;
+    bool narrow = true;
+    for (uint64_t q = 0; q < nreads && narrow; ++q) narrow = offsets[q + 1] - offsets[q] < 65536;
+    if (digest_kind) {
+        // perform_minimizer_digestion / perform_dna_minimizer_digestion (compute_ms_pml.cpp:919-923): the digested
+        // reads never leave the device; the vectors are laid out at the digested offsets
+        const uint64_t cap = spx_digest_capacity(digest_kind, k, total_in);
+        void *dd = nullptr, *ddo = nullptr;
+        if ((rc = ensure_scratch(ix, 0, cap, &dd)) != SPX_OK) return rc;
+        if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &ddo)) != SPX_OK) return rc;
+        rc = spx_digest_batch_device(ix, digest_kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total_in,
+                                     (uint8_t*)dd, cap, (uint64_t*)ddo, nullptr);
+        if (rc != SPX_OK) return rc;
+        SPX_HIP(hipMemcpy(&total, (uint64_t*)ddo + nreads, 8, hipMemcpyDeviceToHost));  // synchronises
+        wseq = (const uint8_t*)dd;
+        woff = (const uint64_t*)ddo;
+    }
+    void *dlen = nullptr, *dptr = nullptr, *ddoc = nullptr, *dcls = nullptr;
+    const bool need_len = want_len || (mode == SPX_MODE_MS && out_class);
+    if (need_len && (rc = ensure_scratch(ix, 2, (total + 8) * 4, &dlen)) != SPX_OK) return rc;
+    if (mode == SPX_MODE_MS && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &dptr)) != SPX_OK) return rc;
+    if (want_doc && (rc = ensure_scratch(ix, 4, (total + 8) * 4, &ddoc)) != SPX_OK) return rc;
+    if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
+    rc = query_device_impl(ix, mode, wseq, woff, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr, (uint32_t*)ddoc,
+                           (spx_class*)dcls, bin_width, max_value_thr, nullptr, narrow);
+    if (rc != SPX_OK) return rc;
+    // count + scan per stream, then ONE read-back of the three sizes
+    const size_t cub = text_scan_bytes(nreads);
+    void* dcub = nullptr;
+    if ((rc = ensure_scratch(ix, 9, cub + 256, &dcub)) != SPX_OK) return rc;
+    const void* vals[3] = {want_len ? dlen : nullptr, want_ptr ? dptr : nullptr, want_doc ? ddoc : nullptr};
+    const int vbytes[3] = {narrow ? 2 : 4, 8, narrow ? 2 : 4};
+    void *lb[3] = {nullptr, nullptr, nullptr}, *ls[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+        out_bytes[i] = 0;
+        ix->text_bytes[i] = 0;
+        if (!vals[i]) continue;
+        if ((rc = ensure_scratch(ix, 10 + i, (nreads + 2) * 8, &lb[i])) != SPX_OK) return rc;
+        if ((rc = ensure_scratch(ix, 13 + i, (nreads + 2) * 8, &ls[i])) != SPX_OK) return rc;
+        if ((rc = launch_text_count(vals[i], vbytes[i], woff, gap ? (const uint32_t*)dgap : nullptr, nreads, (uint64_t*)lb[i],
+                                    (uint64_t*)ls[i], dcub, cub, nullptr)) != SPX_OK)
+            return rc;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (vals[i]) SPX_HIP(hipMemcpy(&out_bytes[i], (uint64_t*)ls[i] + nreads, 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) {
+        if (!vals[i]) continue;
+        void* dtext = nullptr;
+        if ((rc = ensure_scratch(ix, 16 + i, out_bytes[i] + 64, &dtext)) != SPX_OK) return rc;
+        if ((rc = launch_text_write(vals[i], vbytes[i], woff, gap ? (const uint32_t*)dgap : nullptr, nreads,
+                                    (const uint64_t*)ls[i], (char*)dtext, nullptr)) != SPX_OK)
+            return rc;
+        ix->text_bytes[i] = out_bytes[i];
+    }
+    SPX_HIP(hipDeviceSynchronize());
+    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
+    WalkCounters wc;
+    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    if (wc.error) {
+        set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
+                  "thresholds are inconsistent with the BWT)", wc.error);
+        return SPX_E_FORMAT;
+    }
+    ix->text_nreads = nreads;
+    ix->text_ready = true;
+    return SPX_OK;
+}
+
+int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) {
+    if (!ix || !text) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> hg(ix->host_mu);
+    if (!ix->text_ready) {
+        set_error("spx_query_text_fetch without a successful spx_query_text_begin");
+        return SPX_E_ARG;
+    }
+    SPX_HIP(hipSetDevice(ix->device));
+    for (int i = 0; i < 3; ++i) {
+        if (ix->text_bytes[i] == 0) continue;
+        if (text[i]) SPX_HIP(hipMemcpy(text[i], ix->scratch[16 + i].p, ix->text_bytes[i], hipMemcpyDeviceToHost));
+        if (line_start && line_start[i])
+            SPX_HIP(hipMemcpy(line_start[i], ix->scratch[13 + i].p, (ix->text_nreads + 1) * 8, hipMemcpyDeviceToHost));
+    }
+    ix->text_ready = false;
+    return SPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // flat-layout cache (.spx) and replication: the device arrays of an index as they are
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -883,6 +1037,7 @@ struct SpxFileHeader {
     uint64_t arr_offset[spx_index::NARR];  // file offsets, 4096-aligned
     spx::DevIndex view;   // scalars; the pointers inside are rebound on load
     uint64_t device_bytes;
+    char source_tag[128]; // spx_index_set_source_tag(): what the index was built from, as the caller names it
 };
 
 constexpr size_t STAGE = 16u << 20;
@@ -1056,6 +1211,7 @@ int spx_index_save(spx_index* ix, const char* path) {
         h.view = blank.view;
     }
     h.device_bytes = ix->device_bytes;
+    memcpy(h.source_tag, ix->source_tag, sizeof h.source_tag);
     // the fat table and fat_j are not written: spx_index_load_flat rebuilds them from the other arrays (build_fat)
     uint64_t off = (sizeof h + 4095) & ~4095ull;
     for (int i = 0; i < spx_index::NARR; ++i) {
@@ -1117,8 +1273,42 @@ spx_index* spx_index_load_flat(const char* path, int device) {
         fclose(f);
         return nullptr;
     }
+    {   // the header's fields against each other and against the file: a damaged cache must not size device
+        // arrays the kernels then run past
+        struct stat stf;
+        const uint64_t fsize = fstat(fileno(f), &stf) == 0 ? (uint64_t)stf.st_size : 0;
+        const uint64_t r = h.r;
+        const uint64_t row_bytes = h.view.compact ? sizeof(spx::Row32) : sizeof(spx::Row);
+        const bool aux = h.has_samples || h.has_docs;
+        uint64_t want[spx_index::NARR] = {};
+        want[A_ROWS] = (r + ROW_PAD) * row_bytes;
+        want[A_DIRROWS] = (r + ROW_PAD) * sizeof(spx::JumpRow);
+        want[A_FAT] = (h.view.nfat + 2) * (uint64_t)h.view.fat_stride;
+        want[A_FATJ] = h.view.nfat * 4 + 64;
+        want[A_Q] = (r + 1 + Q_PAD) * 4;
+        want[A_AUX] = aux ? (r + 2) * sizeof(spx::Aux) : 0;
+        want[A_SSRUN] = h.has_samples ? (r + 4) * 8 : 0;
+        want[A_RUNDOCS] = h.has_docs ? (r + ROW_PAD) * 4 : 0;
+        want[A_LETTERS] = 256 * sizeof(spx::LetterInfo);
+        want[A_TEXT] = h.n_text ? h.n_text + 16 : 0;
+        bool ok = r > 0 && r < 0xfffffff0ull && h.view.r == r && h.n > 0 && h.view.n == h.n &&
+                  h.view.fat_stride == (aux ? 32u : 16u) && (h.n_text == 0 || h.n_text + 1 == h.n || h.n_text < h.n);
+        for (int i = 0; ok && i < spx_index::NARR; ++i) {
+            ok = h.arr_bytes[i] == want[i];
+            const bool stored = i != A_FAT && i != A_FATJ && h.arr_bytes[i] != 0;
+            if (ok && stored) ok = h.arr_offset[i] >= sizeof h && h.arr_offset[i] + h.arr_bytes[i] <= fsize;
+        }
+        if (!ok) {
+            set_error("%s: the header does not describe a consistent index (array sizes / offsets against r = %llu and the "
+                      "file's %llu bytes): rebuild the cache", path, (unsigned long long)r, (unsigned long long)fsize);
+            fclose(f);
+            return nullptr;
+        }
+    }
     spx_index* ix = new spx_index();
     ix->device = device;
+    h.source_tag[sizeof h.source_tag - 1] = 0;
+    memcpy(ix->source_tag, h.source_tag, sizeof ix->source_tag);
     ix->n = h.n;
     ix->r = h.r;
     ix->has_samples = h.has_samples != 0;
@@ -1197,7 +1387,13 @@ spx_index* spx_index_clone(spx_index* src, int device) {
         bind_view(ix);
         const int rc = init_runtime(ix);
         memcpy(ix->charhash, src->charhash, sizeof ix->charhash);
+        memcpy(ix->source_tag, src->source_tag, sizeof ix->source_tag);
         ix->waves_per_cu = src->waves_per_cu;
+        ix->chunk_mode = src->chunk_mode;
+        ix->chunk_shift = src->chunk_shift;
+        ix->chunk_len = src->chunk_len;
+        ix->force_lanes_per_wave = src->force_lanes_per_wave;
+        ix->force_digest_kernel = src->force_digest_kernel;
         return rc;
     };
     if (body() != SPX_OK) {

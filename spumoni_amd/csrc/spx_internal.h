@@ -154,6 +154,7 @@ struct spx_index {
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
     int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read
     uint8_t charhash[4] = {0, 0, 0, 0};  // -m digestion: 8-bit character hashes of A, C, G, T
+    char source_tag[128] = {0};          // spx_index_set_source_tag(): the caller's fingerprint of the index files
     // host-buffer queries of large batches run as a pipeline over chunks of reads: copy in,
     // walk, copy out on three streams (created on first use)
     static constexpr int PIPE_CHUNKS = 8;
@@ -164,7 +165,11 @@ struct spx_index {
     struct Scratch {
         void* p = nullptr;
         size_t cap = 0;
-    } scratch[8], chunk_scr[9];  // host-buffer queries; chunked walks and the length bits (under mu)
+    } scratch[20], chunk_scr[9];  // host-buffer queries (8..19: text output); chunked walks and the length bits (under mu)
+    // spx_query_text_begin -> spx_query_text_fetch: the streams' sizes and where they wait on the device
+    uint64_t text_bytes[3] = {0, 0, 0};
+    uint64_t text_nreads = 0;
+    bool text_ready = false;
     int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
     int chunk_shift = 0;  // "chunk_shift" option: log2 of the chunk size (0 = automatic)
     int chunk_len = 0;    // "chunk_len" option: chunk size in characters (rounded up to 16; 0 = automatic)
@@ -227,8 +232,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
                       const uint64_t* d_ds, const uint64_t* d_de);
 // spx_walk.hip
+// *wrote_lengths: the walk wrote the PML lengths itself (k_walk_fast): launch_len_expand is not needed
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
-                hipStream_t stream);
+                hipStream_t stream, bool* wrote_lengths = nullptr);
 int launch_ms_extend(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // PML lengths through one bit per character: prepare_len_mask before the walk (sets args.len_mask; nothing
 // to do for MS or a classification-only query), launch_len_expand after it
@@ -238,6 +244,12 @@ int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // qualify and the plain walk should run)
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
                         bool* done);
+// spx_text.hip: the values lines of one vector as text (count + scan, then -- the stream's size known -- the digits)
+int launch_text_count(const void* d_vals, int value_bytes, const uint64_t* d_offs, const uint32_t* d_gap, uint64_t nreads,
+                      uint64_t* d_line_bytes, uint64_t* d_line_start, void* d_cub, size_t cub_bytes, hipStream_t st);
+size_t text_scan_bytes(uint64_t nreads);
+int launch_text_write(const void* d_vals, int value_bytes, const uint64_t* d_offs, const uint32_t* d_gap, uint64_t nreads,
+                      const uint64_t* d_line_start, char* d_text, hipStream_t st);
 // spx_digest.hip: d_out_offs gets nreads + 1 offsets, d_out the digested reads (capacity is the
 // caller's business: spx_digest_capacity)
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,

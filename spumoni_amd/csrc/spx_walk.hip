@@ -1081,7 +1081,7 @@ __global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_t
 }
 
 template <int MODE, bool DOC, bool COMPACT, bool NARROW, int CHUNK = 0>
-int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint64_t items = 0) {
+int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint64_t items = 0, bool* wrote_lengths = nullptr) {
     if (CHUNK == 0) items = args.nreads;
     if (CHUNK == 0 && MODE == SPX_MODE_PML && args.out_lengths != nullptr && args.len_mask == nullptr) {
         set_error("internal: PML walk without prepare_len_mask");
@@ -1147,9 +1147,10 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         grid = (items + lpw - 1) / lpw;
     }
     if (grid == 0) grid = 1;
-    if (fast)
+    if (fast) {
         k_walk_fast<MODE, DOC, NARROW><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
-    else
+        if (wrote_lengths) *wrote_lengths = MODE == SPX_MODE_PML;  // no bit mask, no expansion kernel
+    } else
         k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
@@ -1604,15 +1605,16 @@ int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream) 
 }
 
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
-                hipStream_t stream) {
+                hipStream_t stream, bool* wrote_lengths) {
     (void)total_chars;
+    if (wrote_lengths) *wrote_lengths = false;
     const bool doc = args.out_docs != nullptr;
     // pick the instantiation: mode x doc x row encoding x output width
     const int sel = (mode == SPX_MODE_MS ? 8 : 0) | (doc ? 4 : 0) | (ix->view.compact ? 2 : 0) | (args.narrow ? 1 : 0);
     switch (sel) {
 #define SPX_CASE(n, M, D, C, N) \
     case n:                     \
-        return launch_lanes<M, D, C, N>(ix, args, stream);
+        return launch_lanes<M, D, C, N>(ix, args, stream, 0, wrote_lengths);
         SPX_CASE(0, SPX_MODE_PML, false, false, false)
         SPX_CASE(1, SPX_MODE_PML, false, false, true)
         SPX_CASE(2, SPX_MODE_PML, false, true, false)

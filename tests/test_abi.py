@@ -50,6 +50,6 @@ def test_product_does_not_touch_the_oracle():
     pkg = os.path.join(ROOT, "spumoni_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp", "Makefile")):
+            if f.endswith((".py", ".hip", ".inc", ".cpp", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt, os.path.join(dp, f)

@@ -115,3 +115,43 @@ def test_text_rebuilt_from_the_index_is_the_text(oracle_mod, seed, letters, wide
     pml_only = capi.Index.from_raw(synth.RawIndex(heads=raw.heads, lens=raw.lens, thr=raw.thr, n=raw.n), 0)
     with pytest.raises(capi.SpxError, match="SA samples"):
         pml_only.rebuild_text()
+
+
+def test_source_tag_travels_with_cache_and_clone(tmp_path):
+    """nothing tied a .spx cache to the index files it was written for.  The caller's fingerprint of
+    those files is saved in the header and handed back on load (the CLI refuses a cache whose tag differs)."""
+    raw = synth.statistical_rlbwt(3000, 20, 4.0, seed=2, device="cuda")
+    ix = capi.Index.from_raw(raw, 0)
+    assert ix.source_tag() == ""
+    ix.set_source_tag("pml:3 files:0123456789abcdef")
+    p = str(tmp_path / "t.spx")
+    ix.save(p)
+    assert capi.Index.load_flat(p, 0).source_tag() == "pml:3 files:0123456789abcdef"
+    assert ix.clone(0).source_tag() == "pml:3 files:0123456789abcdef"
+    ix.set_source_tag("x" * 500)  # cut to what the header holds
+    assert ix.source_tag() == "x" * 127
+
+
+def test_damaged_cache_header_is_refused(tmp_path):
+    """spx_index_load_flat trusted the header's array sizes / offsets; a damaged file could size device
+    arrays the kernels then run past.  The fields are checked against each other and against the file."""
+    import struct
+
+    raw = synth.statistical_rlbwt(2000, 12, 4.0, seed=5, device="cuda", with_samples=True, n_docs=3)
+    ix = capi.Index.from_raw(raw, 0)
+    p = str(tmp_path / "d.spx")
+    ix.save(p)
+    good = open(p, "rb").read()
+    assert capi.Index.load_flat(p, 0).r == ix.r
+    # header: magic 8, layout 56, header_bytes 8, n 8, r 8, has_samples 4, has_docs 4, n_text 8, arr_bytes[10] ...
+    off_r, off_arr = 8 + 56 + 8 + 8, 8 + 56 + 8 + 8 + 8 + 4 + 4 + 8
+    for name, (at, val) in {"r": (off_r, ix.r + 1000), "rows bytes": (off_arr, 64), "dirrows bytes": (off_arr + 8, 1 << 40),
+                            "rows offset": (off_arr + 80, len(good) + 4096)}.items():
+        blob = bytearray(good)
+        blob[at:at + 8] = struct.pack("<Q", val)
+        open(p, "wb").write(bytes(blob))
+        with pytest.raises(capi.SpxError, match="consistent"):
+            capi.Index.load_flat(p, 0)
+    open(p, "wb").write(good[: len(good) // 2])  # truncated
+    with pytest.raises(capi.SpxError):
+        capi.Index.load_flat(p, 0)

@@ -342,3 +342,33 @@ def test_cli_ms_without_a_text_file(built, tmp_path):
     Without SPUMONI_TEXT the text is rebuilt from the MS index: .lengths / .pointers / .doc_numbers / .report identical."""
     ref, prefix, seqs, offs, rng = _setup(tmp_path, 47, list(b"ACGT"))
     _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d"], "-M", give_text=False)
+
+
+def test_stale_cache_is_not_used(tmp_path):
+    """with SPUMONI_CACHE=use a leftover <ref>.pml.spx was loaded whatever index files lay next to it.
+    The cache now carries a fingerprint of the files it was written for: rebuild the index under the same
+    prefix and `run` flattens the new files (and says why) instead of answering for the old index."""
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 91, list(b"ACGT"))
+    a_dir = tmp_path / "gpu"
+    a_dir.mkdir()
+    _write_fasta(a_dir / "reads.fa", seqs, offs, np.random.default_rng(1))
+
+    def run(policy):
+        env = dict(os.environ, SPUMONI_CACHE=policy)
+        r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(a_dir / "reads.fa"), "-n", "-P", "-c"],
+                           capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        return r.stderr.decode(), open(str(a_dir / "reads.fa") + ".pseudo_lengths", "rb").read()
+
+    err, first = run("write")
+    assert os.path.exists(prefix + ".pml.spx") and "stale" not in err
+    err, again = run("use")
+    assert again == first and "stale" not in err
+    # another index under the same prefix (other text, other runs): the cache on disk belongs to the old one
+    raw2, text2 = cases.real_case(92, 5000, list(b"ACGT"), ndocs=4)
+    raw2.write_raw_files(prefix)
+    err, third = run("use")
+    assert "stale" in err
+    os.remove(prefix + ".pml.spx")
+    err, fresh = run("off")
+    assert third == fresh and third != first

@@ -14,7 +14,7 @@ src, bench_json, out = sys.argv[1:4]
 def mean_counter(sub, name):
     """per step: the walk's dispatch plus the dispatch that writes the lengths out from the walk's reset bits"""
     total, n = None, 0
-    for kernel in ("k_walk_lanes", "k_expand_lengths"):
+    for kernel in ("k_walk_fast", "k_walk_lanes", "k_expand_lengths"):
         vals = []
         for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
@@ -36,7 +36,7 @@ tj = {
     "key": b["roofline"]["traffic_key"],
     "hbm_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh), mean over {nf} "
-              f"k_walk_lanes (+ k_expand_lengths) dispatches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`: "
+              f"k_walk_fast (k_walk_lanes + k_expand_lengths where the state machine runs) dispatches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`: "
               f"FETCH_SIZE {fetch:.4g} KB (x2: gfx950 counts a 128-B line fill as 64 B), WRITE_SIZE {write:.4g} KB"
               + (f", TCC_EA0_RDREQ {rd:.4g}" if rd else ""),
 }

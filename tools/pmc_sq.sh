@@ -12,6 +12,6 @@ for row in csv.DictReader(open(sys.argv[1])):
     agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
     if row["Counter_Name"] == "SQ_WAVE_CYCLES": cnt[k] += 1
 for k, v in agg.items():
-    if "walk" in k or "digest" in k:
+    if "walk" in k or "digest" in k or "expand" in k:
         print(k, cnt[k], {a: "%.3e" % (b / cnt[k]) for a, b in sorted(v.items())})
 PY

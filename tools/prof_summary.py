@@ -17,7 +17,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
         rows = list(csv.reader(open(f)))
         h = rows[0]
         kn, cn, cv = h.index("Kernel_Name"), h.index("Counter_Name"), h.index("Counter_Value")
-        for kernel in ("k_walk_lanes", "k_expand_lengths"):
+        for kernel in ("k_walk_fast", "k_walk_lanes", "k_expand_lengths"):
             agg = defaultdict(list)
             for r in rows[1:]:
                 if kernel in r[kn]:
