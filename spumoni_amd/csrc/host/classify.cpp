@@ -219,6 +219,34 @@ struct TextBuf {
     void clear() { len = 0; }
 };
 
+// Page-locked blocks made ahead of time.  Locking pages is slow (~4 GB/s: a super-batch's 64 MB of reads and
+// 160 MB of text cost 50 ms per slot the first time a slot is used, a quarter of a second in a 1-second run),
+// so the blocks the slots will want are allocated on a helper thread while the index loads (prepare_pinned_pool)
+// and PinnedBuf takes them from here.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> blocks;
+    void* take(size_t want, size_t& got) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].second >= want && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void* p = blocks[best].first;
+        got = blocks[best].second;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    void put(void* p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        blocks.emplace_back(p, bytes);
+    }
+    ~PinnedPool() {
+        for (auto& b : blocks) spx_host_free(b.first);
+    }
+};
+PinnedPool g_pinned_pool;
+
 // grow-only buffer in page-locked host memory (spx_host_alloc): copies to and from the GPU
 // then run at PCIe DMA speed (171 vs 42 M reads/s through spx_query_batch on the bench shape)
 template <class T>
@@ -232,7 +260,12 @@ struct PinnedBuf {
     void reserve(size_t want) {
         if (want <= cap) return;
         size_t nc = std::max(want, cap * 2);
-        T* q = (T*)spx_host_alloc(nc * sizeof(T));
+        size_t got = 0;
+        T* q = (T*)g_pinned_pool.take(nc * sizeof(T), got);
+        if (q)
+            nc = got / sizeof(T);
+        else
+            q = (T*)spx_host_alloc(nc * sizeof(T));
         if (!q) fatal_error("%s", spx_last_error());
         if (n) std::memcpy(q, p, n * sizeof(T));
         spx_host_free(p);
@@ -606,6 +639,7 @@ struct Slot {
     Results res;
     uint64_t seq = 0;            // position of this super-batch in the input (results are written in this order)
     bool last = false;           // no more input after this one
+    std::vector<std::vector<ParsedRead>> parsed;  // fill_slot's per-thread reads (kept: their capacity is reused)
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
 };
@@ -636,7 +670,11 @@ private:
 // the super-batch parsed by several threads, reads upper-cased while they are copied into the
 // page-locked buffer.  A malformed / empty read truncates the super-batch there and is reported
 // after everything before it has been written, like the reference running read by read.
+double g_parse_s[4] = {0, 0, 0, 0};  // fill_slot: segmentation (serial), parse, placement (serial), copy
 void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_done) {
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    auto t_phase = tick();
     slot.sb.clear();
     slot.last = false;
     slot.deferred = 0;
@@ -652,8 +690,12 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
         ranges.push_back(r);
     }
     slot.last = input_done;
+    g_parse_s[0] += since(t_phase);
+    t_phase = tick();
     const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (ranges.size() + 63) / 64));
-    std::vector<std::vector<ParsedRead>> parsed(nt);
+    std::vector<std::vector<ParsedRead>>& parsed = slot.parsed;
+    if (parsed.size() < nt) parsed.resize(nt);
+    for (auto& v : parsed) v.clear();
     std::vector<ReadFile::ParseError> errs(nt);
     std::vector<size_t> err_at(nt, 0);
     auto work = [&](size_t t) {
@@ -664,6 +706,8 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
     for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    g_parse_s[1] += since(t_phase);
+    t_phase = tick();
     // where does every thread's part go, and where is the first problem (if any)?
     std::vector<size_t> take(nt, 0), chars(nt, 0);
     for (size_t t = 0; t < nt && !slot.deferred; ++t) {
@@ -692,6 +736,8 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
     slot.sb.offs.resize(nreads + 1);
     slot.sb.offs[0] = 0;
     slot.sb.seqs.resize_uninit(nchars);
+    g_parse_s[2] += since(t_phase);
+    t_phase = tick();
     auto assemble = [&](size_t t) {
         size_t rdx = r0[t], cpos = c0[t];
         for (size_t q = 0; q < take[t]; ++q) {
@@ -714,6 +760,7 @@ void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_don
     for (size_t t = 1; t < nt; ++t) th.emplace_back(assemble, t);
     assemble(0);
     for (auto& x : th) x.join();
+    g_parse_s[3] += since(t_phase);
 }
 
 }  // namespace
@@ -754,6 +801,38 @@ private:
     std::condition_variable cv_;
     std::vector<std::pair<uint64_t, int>> done_;
 };
+
+// Called on a helper thread while the index loads: the page-locked blocks the slots of classify_reads will ask for
+// (per slot: the reads of a super-batch, and per output stream its text and its record offsets).
+void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
+    if (spx_device_count() <= 0) return;
+    const size_t nslots = 2 * std::max<size_t>(ndev, 1) + 2;
+    const bool report_only = o.report_only && !o.ms && o.write_report;
+    const size_t chars = o.super_batch_chars + (4u << 20);
+    std::vector<size_t> sizes;
+    for (size_t i = 0; i < nslots; ++i) {
+        sizes.push_back(chars);  // reads
+        if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
+        const size_t reads_guess = chars / 100 + 4096;
+        if (!report_only) {  // lengths: "<value> " is 2-4 bytes for most values
+            sizes.push_back(chars * 3 + (8u << 20));
+            sizes.push_back((reads_guess + 1) * 8);
+        }
+        if (o.ms) {  // pointers: up to 13 digits
+            sizes.push_back(chars * 12);
+            sizes.push_back((reads_guess + 1) * 8);
+        }
+        if (o.use_doc) {
+            sizes.push_back(chars * 3);
+            sizes.push_back((reads_guess + 1) * 8);
+        }
+    }
+    for (size_t b : sizes) {
+        void* p = spx_host_alloc(b);
+        if (!p) return;  // (the slots then allocate what they need themselves)
+        g_pinned_pool.put(p, b);
+    }
+}
 
 size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     Outputs out;
@@ -847,6 +926,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     // per-stage wall times (ours, additive; stages overlap, so they do not add up to the total)
     for (StageTimer* t : {&t_load, &t_parse, &t_write})
         std::fprintf(stderr, "[timing] %-22s %.3f s\n", t->name, t->total);
+    std::fprintf(stderr, "[timing]   segmentation %.3f  parse %.3f  placement %.3f  copy %.3f s\n", g_parse_s[0], g_parse_s[1],
+                 g_parse_s[2], g_parse_s[3]);
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "  of which formatting", g_format_s);
     for (size_t d = 0; d < ndev; ++d)
         std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)\n", d,

@@ -54,6 +54,8 @@ size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promot
 // preloaded: the reads file, already mapped (while the index was loading); nullptr = map it here.
 class ReadFile;
 size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded = nullptr);
+// page-locked buffers for the slots of classify_reads, made ahead of time (a helper thread, while the index loads)
+void prepare_pinned_pool(const RunOptions& o, size_t ndev);
 // general-text driver (:1219-1297): reads separated by \x01, named read_<i>
 size_t classify_general_reads(IndexSet& set, const RunOptions& o);
 

@@ -101,7 +101,25 @@ bool ReadFile::next_batch(size_t num_bases, std::vector<ParsedRead>& out) {
     return true;
 }
 
+void ReadFile::precompute_ranges(size_t num_bases) {
+    ranges_.clear();
+    Range r;
+    while (next_range_scan(num_bases, r)) ranges_.push_back(r);
+    ranges_bases_ = num_bases;
+    ranges_next_ = 0;
+    ranges_ready_ = true;
+}
+
 bool ReadFile::next_range(size_t num_bases, Range& out) {
+    if (ranges_ready_ && num_bases == ranges_bases_) {
+        if (ranges_next_ >= ranges_.size()) return false;
+        out = ranges_[ranges_next_++];
+        return true;
+    }
+    return next_range_scan(num_bases, out);
+}
+
+bool ReadFile::next_range_scan(size_t num_bases, Range& out) {
     // input type sniffing (batch_loader.cpp:30-38)
     if (format_ == ReadFormat::NotClear) {
         if (size_ == 0) return false;

@@ -55,6 +55,9 @@ public:
         std::string message;  // printed with the FATAL_ERROR shape
     };
     bool next_range(size_t num_bases, Range& out);
+    // The whole file's segmentation ahead of time (it is sequential, ~25 ns per line: 0.1 s for 4 * 10^6 reads):
+    // done on the thread that maps the file while the index loads; next_range(num_bases) then hands the ranges out.
+    void precompute_ranges(size_t num_bases);
     void parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const;
 
     ReadFormat format() const { return format_; }
@@ -67,6 +70,11 @@ private:
     size_t next_line_ = 0;  // first line not yet consumed by a batch
     bool eof_ = false;      // the reference stream would no longer be good()
     ReadFormat format_ = ReadFormat::NotClear;
+
+    std::vector<Range> ranges_;  // precompute_ranges()
+    size_t ranges_bases_ = 0, ranges_next_ = 0;
+    bool ranges_ready_ = false;
+    bool next_range_scan(size_t num_bases, Range& out);
 
     size_t line_count() const { return line_start_.size() - 1; }
     size_t line_len(size_t i) const { return line_start_[i + 1] - 1 - line_start_[i]; }

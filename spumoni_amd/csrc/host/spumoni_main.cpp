@@ -194,12 +194,16 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
         reads_loader = std::thread([&] {
             try {
                 reads.reset(new ReadFile(o.pattern_file, (unsigned)o.format_threads));
+                reads->precompute_ranges(1000);  // reader.loadBatch(input_file, 1000)   (compute_ms_pml.cpp:903)
             } catch (const std::exception& e) {
                 reads_err = e.what();
             }
         });
+    std::thread pinned_loader;
+    if (!o.is_general_text) pinned_loader = std::thread([&] { prepare_pinned_pool(o, std::max<size_t>(o.devices.size(), 1)); });
     set.load(o);
     if (reads_loader.joinable()) reads_loader.join();
+    if (pinned_loader.joinable()) pinned_loader.join();
     if (!reads_err.empty()) fatal_error("%s", reads_err.c_str());
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     std::cout << std::endl;

@@ -920,6 +920,16 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     std::lock_guard<std::mutex> hg(ix->host_mu);
     ix->text_ready = false;
     SPX_HIP(hipSetDevice(ix->device));
+    static const bool timing = getenv("SPX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[spx] text_begin: %-28s %.2f ms\n", what, (t - t_mark) * 1e3);
+        t_mark = t;
+    };
     const uint64_t total_in = nreads ? offsets[nreads] : 0;
     void *dseq = nullptr, *doff = nullptr, *dgap = nullptr;
     const uint64_t padded = ((total_in + 3) / 4) * 4 + 32;
@@ -930,6 +940,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     SPX_HIP(hipMemset((char*)dseq + total_in, 0, padded - total_in));
     SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
     if (gap) SPX_HIP(hipMemcpy(dgap, gap, nreads * 4, hipMemcpyHostToDevice));
+    lap("copy in");
     const uint8_t* wseq = (const uint8_t*)dseq;
     const uint64_t* woff = (const uint64_t*)doff;
     uint64_t total = total_in;
@@ -958,6 +969,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     rc = query_device_impl(ix, mode, wseq, woff, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr, (uint32_t*)ddoc,
                            (spx_class*)dcls, bin_width, max_value_thr, nullptr, narrow);
     if (rc != SPX_OK) return rc;
+    lap("[digest +] walk");
     // count + scan per stream, then ONE read-back of the three sizes
     const size_t cub = text_scan_bytes(nreads);
     void* dcub = nullptr;
@@ -977,6 +989,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     }
     for (int i = 0; i < 3; ++i)
         if (vals[i]) SPX_HIP(hipMemcpy(&out_bytes[i], (uint64_t*)ls[i] + nreads, 8, hipMemcpyDeviceToHost));
+    lap("count + scan");
     for (int i = 0; i < 3; ++i) {
         if (!vals[i]) continue;
         void* dtext = nullptr;
@@ -987,6 +1000,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         ix->text_bytes[i] = out_bytes[i];
     }
     SPX_HIP(hipDeviceSynchronize());
+    lap("digits");
     if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
     WalkCounters wc;
     SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
@@ -1011,6 +1025,8 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
         return SPX_E_ARG;
     }
     SPX_HIP(hipSetDevice(ix->device));
+    static const bool timing = getenv("SPX_TIMING") != nullptr;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     for (int i = 0; i < 3; ++i) {
         if (ix->text_bytes[i] == 0) continue;
         if (text[i]) SPX_HIP(hipMemcpy(text[i], ix->scratch[16 + i].p, ix->text_bytes[i], hipMemcpyDeviceToHost));
@@ -1018,6 +1034,10 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
             SPX_HIP(hipMemcpy(line_start[i], ix->scratch[13 + i].p, (ix->text_nreads + 1) * 8, hipMemcpyDeviceToHost));
     }
     ix->text_ready = false;
+    if (timing)
+        fprintf(stderr, "[spx] text_fetch: %.2f ms for %.1f MB\n",
+                (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3,
+                (ix->text_bytes[0] + ix->text_bytes[1] + ix->text_bytes[2]) / 1e6);
     return SPX_OK;
 }
 

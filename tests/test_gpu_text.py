@@ -46,7 +46,7 @@ def test_text_streams_are_the_reference_bytes(oracle_mod, seed, letters):
     f, a, b, s = oracle_mod.classify(lens, offs, 20, 6)
     assert np.array_equal(got["class"]["above"], a) and np.array_equal(got["class"]["below"], b)
     # MS: lengths, pointers (up to 13 digits), document ids
-    ix.set_text(text)
+    ix.set_text(__import__("torch").from_numpy(text.copy()))
     w = orc.ms(seqs, offs, want_docs=True, text=text)
     got = ix.query_text(capi.SPX_MODE_MS, seqs, offs, gap, capi.SPX_TEXT_LENGTHS | capi.SPX_TEXT_POINTERS | capi.SPX_TEXT_DOCS)
     for i, key in enumerate(("lengths", "pointers", "docs")):

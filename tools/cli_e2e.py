@@ -68,6 +68,12 @@ def run(tag, reads, extra_env):
 run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
 run("flat-layout cache", f"{d}/reads.fa", {})
 run("flat-layout cache, again", f"{d}/reads.fa", {})
+run("flat-layout cache, SPUMONI_HOST_FORMAT=1 (round 2: values over PCIe, digits on the host)", f"{d}/reads.fa", {"SPUMONI_HOST_FORMAT": "1"})
+os.replace(f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths")
+run("flat-layout cache, text from the device again", f"{d}/reads.fa", {})
+print("   cmp host-formatted against device-formatted .pseudo_lengths:",
+      "identical" if subprocess.run(["cmp", f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths"]).returncode == 0 else "DIFFERENT", flush=True)
+os.remove(f"{d}/host_format.pseudo_lengths")
 run("SPUMONI_GPUS=0,0 (two workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0"})
 run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
 # ---- CPU: the oracle harness, file to file, one thread (the reference's -t 1 shape) ----

@@ -1,6 +1,14 @@
 #!/bin/bash
-lib=spumoni_amd/libspumoni_gpu.so
-for old in "" 1; do
-  echo "== SPX_OLD_WALK=$old"
-  env ${old:+SPX_OLD_WALK=1} SPUMONI_GPU_LIB=$PWD/$lib python tools/sweep.py ms 2>&1 | grep -E "Gsteps" | cut -c1-190
-done
+# one CLI run with the library's stage timing
+python - <<'PY'
+import os, subprocess, sys, time
+sys.path.insert(0, os.getcwd())
+os.environ["E2E_READS"] = "4000000"; os.environ["E2E_CPU_READS"] = "1000"
+__file__ = os.path.join(os.getcwd(), "tools", "cli_e2e.py")
+src = open("tools/cli_e2e.py").read().split('run("raw index files')[0]
+exec(src)
+for env in ({"SPUMONI_CACHE": "write"}, {}, {"SPUMONI_HOST_FORMAT": "1"}):
+    e = dict(os.environ, **env)
+    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", f"{d}/reads.fa", "-P", "-c", "-n"], capture_output=True, env=e)
+    print(r.stderr.decode()[-3500:])
+PY
