@@ -194,8 +194,10 @@ int spx_query_batch(spx_index *ix, int mode, const uint8_t *seqs, const uint64_t
  * aligned (results are written as 16-byte vectors).  total_chars is
  * d_offsets[nreads] - d_offsets[0] or an upper bound of it (reads digested on
  * the device: the bound of spx_digest_capacity does); it sizes internal
- * scratch, and a batch that holds more characters than it says is reported
- * through spx_last_walk_stats (SPX_E_FORMAT), results undefined.             */
+ * scratch (the chunked walk of long-read batches, the state-machine walk's
+ * length bits), and a batch that holds more characters than it says is then
+ * reported through spx_last_walk_stats (SPX_E_FORMAT), results undefined.  (The
+ * plain walk over compact rows needs no such scratch and is right regardless.) */
 int spx_query_batch_device(spx_index *ix, int mode, const uint8_t *d_seqs,
                            const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars,
                            uint32_t *d_out_lengths, uint64_t *d_out_pointers,
