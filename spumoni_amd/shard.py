@@ -42,12 +42,14 @@ def shard(seqs, offs, lo: int, hi: int):
 
 def class_counts(above, below, nbases: int) -> torch.Tensor:
     """[reads, bases, FOUND, NOT_PRESENT] of one shard; FOUND iff above/(above+below) > 0.5
-    (compute_ms_pml.cpp:993)."""
+    (compute_ms_pml.cpp:993).  Stays on the device of `above` (no host round trip: the caller may be inside a timed
+    region)."""
     above = torch.as_tensor(above).to(torch.int64)
     below = torch.as_tensor(below).to(torch.int64)
-    found = int((2 * above > above + below).sum())
     n = int(above.numel())
-    return torch.tensor([n, int(nbases), found, n - found], dtype=torch.int64)
+    found = (2 * above > above + below).sum().to(torch.int64).reshape(1)
+    fixed = torch.tensor([n, int(nbases)], dtype=torch.int64, device=found.device)
+    return torch.cat([fixed, found, n - found])
 
 
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
