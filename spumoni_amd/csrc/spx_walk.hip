@@ -1090,13 +1090,14 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     // the plain walk over compact rows has a body of its own (spx_walk_fast.inc); SPX_OLD_WALK=1 keeps the state
     // machine for it too (A/B runs, and the tests that hold the two against each other)
     static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
-    const bool fast = COMPACT && CHUNK == 0 && args.only_flagged == nullptr && !old_walk && args.nreads < (1ull << 31);
+    constexpr int FCHUNK = CHUNK == 1 ? 1 : 0;  // k_walk_fast also walks pass 1 of the chunked walk; pass 2 is the state machine's
+    const bool fast = COMPACT && CHUNK <= 1 && args.only_flagged == nullptr && !old_walk && items < (1ull << 31);
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = (fast ? 4 : 0) + MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {
         int occ = 0;
         if (fast)
-            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_fast<MODE, DOC, NARROW>, WALK_TPB, 0));
+            SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_fast<MODE, DOC, NARROW, 0>, WALK_TPB, 0));
         else
             SPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_walk_lanes<MODE, DOC, COMPACT, NARROW, 0>, WALK_TPB, 0));
         ix->occ_blocks[slot] = occ < 1 ? 1 : occ;
@@ -1148,7 +1149,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     }
     if (grid == 0) grid = 1;
     if (fast) {
-        k_walk_fast<MODE, DOC, NARROW><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+        k_walk_fast<MODE, DOC, NARROW, FCHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
         if (wrote_lengths) *wrote_lengths = MODE == SPX_MODE_PML;  // no bit mask, no expansion kernel
     } else
         k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);

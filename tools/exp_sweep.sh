@@ -1,6 +1,6 @@
 #!/bin/bash
-for lib in spumoni_amd/libspumoni_gpu.so spumoni_amd/libspumoni_gpu_prev.so; do
-  echo "== $lib"
-  SPUMONI_GPU_LIB=$PWD/$lib MS_BENCH_BITS=16 python tools/ms_bench.py 2>&1 | grep -E "doc:"
-  SPUMONI_GPU_LIB=$PWD/$lib python tools/sweep.py ms 2>&1 | grep -E "Gsteps" | cut -c1-190
+for old in "" 1; do
+  echo "== SPX_OLD_WALK=$old"
+  env ${old:+SPX_OLD_WALK=1} python tools/sweep.py long 2>&1 | grep -E "auto" | cut -c1-200
+  env ${old:+SPX_OLD_WALK=1} python tools/sweep.py longdna 2>&1 | grep -E "\[0/" | cut -c1-200
 done
