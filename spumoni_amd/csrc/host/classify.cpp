@@ -133,9 +133,12 @@ void IndexSet::load(const RunOptions& o) {
     ix.push_back(first);
     if (spx_index_stats(first, &n, &r) != SPX_OK) fatal_error("%s", spx_last_error());
     for (size_t d = 1; d < o.devices.size(); ++d) {
+        const auto t0 = std::chrono::steady_clock::now();
         spx_index* p = spx_index_clone(first, o.devices[d]);
         if (!p) fatal_error("%s", spx_last_error());
         ix.push_back(p);
+        std::fprintf(stderr, "[timing] index replica on device %d (copied from device %d)  %.3f s\n", o.devices[d], dev0,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
 }
 

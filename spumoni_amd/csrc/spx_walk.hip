@@ -1539,6 +1539,9 @@ __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, 
     if (pair0 + (nw + 1) / 2 > b.len_mask_pairs) return;  // more characters than total_chars said: the walk reported it
     const uint64_t* const mw = b.len_mask + 2 * pair0;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(b.out_lengths);
+    // the first reset at or after a position, remembered across the lane's groups: a long reset-free stretch is scanned
+    // once, not once per group of 8 (a matching stretch of g characters cost g^2 / 512 word loads)
+    uint64_t far_from = ~0ull, far_is = 0;
     for (uint64_t G = (base >> 3) + j; G <= ((end - 1) >> 3); G += lpr) {
         const uint64_t glo = G * 8 < base ? base : G * 8, ghi = G * 8 + 8 > end ? end : G * 8 + 8;
         const uint32_t cnt = (uint32_t)(ghi - glo);  // 8 but for the read's first and last group
@@ -1547,7 +1550,14 @@ __global__ void __launch_bounds__(WALK_TPB) k_expand_lengths(const BatchArgs b, 
         uint64_t bits = mw[w] >> s;  // resets of characters p .. p + 63
         if (s != 0 && w + 1 < nw) bits |= mw[w + 1] << (64 - s);
         uint64_t far = 0;  // first reset at or after p + 64 (only when the window holds none for the last element)
-        if ((bits >> (cnt - 1)) == 0) far = next_reset(mw, nw, p + 64, m);
+        if ((bits >> (cnt - 1)) == 0) {
+            // no reset in [far_from, far_is): the answer for any start in that range is far_is
+            if (!(far_from != ~0ull && p + 64 >= far_from && p + 64 <= far_is)) {
+                far_from = p + 64;
+                far_is = next_reset(mw, nw, p + 64, m);
+            }
+            far = far_is;
+        }
         uint32_t v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
