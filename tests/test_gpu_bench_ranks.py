@@ -68,3 +68,27 @@ def test_more_ranks_than_gpus_is_a_clear_error():
                        capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert "wants GPU" in p.stderr and "the node has" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_one_rank_under_torchrun_with_rccl():
+    """The launcher the driver uses (python -m torch.distributed.run ... bench.py --gpus N) with the RCCL backend, at the
+    one world size a one-GPU box allows: process-group initialisation on the device, the count all-reduce, the
+    barriers and the all-gather of the per-rank step times go through RCCL (backend "nccl" IS RCCL on ROCm)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPX_INDEX_BUDGET_GB="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BENCH_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["classified"]["reads"] == 200000
+    assert d["config"]["classified"] == _bench(["--gpus", "1"])["config"]["classified"]
