@@ -932,9 +932,15 @@ __device__ __forceinline__ uint64_t load8_unaligned(const uint8_t* base, uint64_
 // for each of its 64 reads cooperatively -- 16 consecutive lanes take 16 consecutive pointers of one read, one
 // line -- and every lane then takes its own column of the tile from LDS.
 constexpr int EXT_TPB = 64;  // one wavefront per block: __syncthreads() is a wavefront barrier
-constexpr int EXT_PT = 16;   // pointers per read and tile
+#ifndef SPX_EXT_PT
+#define SPX_EXT_PT 16
+#endif
+#ifndef SPX_EXT_WAVES
+#define SPX_EXT_WAVES 1
+#endif
+constexpr int EXT_PT = SPX_EXT_PT;   // pointers per read and tile
 
-__global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const BatchArgs b) {
+__global__ void __launch_bounds__(EXT_TPB, SPX_EXT_WAVES) k_ms_extend(const DevIndex ix, const BatchArgs b) {
     __shared__ uint64_t s_ptr[EXT_PT][EXT_TPB + 1];
     __shared__ uint64_t s_at[EXT_TPB];   // where each lane's tile starts in out_pointers
     __shared__ uint32_t s_cnt[EXT_TPB];  // pointers of the tile that exist
@@ -968,7 +974,7 @@ __global__ void __launch_bounds__(EXT_TPB) k_ms_extend(const DevIndex ix, const 
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < EXT_TPB * EXT_PT / EXT_TPB; ++p) {  // 16 passes of 4 reads x 16 pointers
-            const uint32_t R = (uint32_t)p * (EXT_TPB / EXT_PT) + (lane >> 4), j = lane & (EXT_PT - 1);
+            const uint32_t R = (uint32_t)p * (EXT_TPB / EXT_PT) + lane / EXT_PT, j = lane & (EXT_PT - 1);
             if (j < s_cnt[R]) s_ptr[j][R] = b.out_pointers[s_at[R] + j];
         }
         __syncthreads();

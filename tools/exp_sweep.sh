@@ -1,6 +1,4 @@
 #!/bin/bash
-for old in "" 1; do
-  echo "== SPX_OLD_WALK=$old"
-  env ${old:+SPX_OLD_WALK=1} python tools/sweep.py long 2>&1 | grep -E "auto" | cut -c1-200
-  env ${old:+SPX_OLD_WALK=1} python tools/sweep.py longdna 2>&1 | grep -E "\[0/" | cut -c1-200
-done
+for rep in 1 2; do for lib in spumoni_amd/libspumoni_gpu*.so; do
+  echo -n "$lib: "; SPUMONI_GPU_LIB=$PWD/$lib MS_BENCH_BITS=16 python tools/ms_bench.py 2>&1 | grep -E "MS \+doc:"
+done; done
