@@ -405,3 +405,18 @@ def test_lengths_from_reset_bits_edge_shapes(gpu, oracle_mod, bits):
     wl, wd = orc.pml(seqs, offs, want_docs=True)
     gd = ix.query_host(capi.SPX_MODE_PML, seqs, offs, want_docs=True, bits=bits)
     assert np.array_equal(gd["lengths"], wl) and np.array_equal(gd["docs"], wd)
+
+
+@pytest.mark.parametrize("lpw", [1, 5, 33, 64])
+@pytest.mark.parametrize("waves", [4, 28])
+def test_lane_and_occupancy_knobs_do_not_change_results(gpu, oracle_mod, lpw, waves):
+    """`lanes_per_wave` (1 = the "one wavefront owns one read" mapping of SURVEY 7.1) and `waves_per_cu`: launch
+    geometry only.  With fewer active lanes per wavefront the idle lanes still take part in the wavefront-wide
+    stores of the lengths and MS pointers (k_walk_fast): every mode against the oracle."""
+    raw, text = cases.real_case(81, 7000, [3, 4, 5, 90, 127, 128, 129, 200, 255], ndocs=4)
+    rng = np.random.default_rng(8)
+    seqs, offs = cases.reads_mixed(rng, text, [3, 4, 5, 90, 127, 128, 129, 200, 255], 150, 300, [2])
+    ix = capi.Index.from_raw(raw, 0)
+    ix.set_option("lanes_per_wave", lpw)
+    ix.set_option("waves_per_cu", waves)
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
