@@ -1,4 +1,14 @@
 #!/bin/bash
-for rep in 1 2; do for lib in spumoni_amd/libspumoni_gpu*.so; do
-  echo -n "$lib: "; SPUMONI_GPU_LIB=$PWD/$lib MS_BENCH_BITS=16 python tools/ms_bench.py 2>&1 | grep -E "MS \+doc:"
-done; done
+# CLI runs: mapped tail against one pwrite per stream
+python - <<'PY'
+import os, subprocess, sys, time
+sys.path.insert(0, os.getcwd())
+os.environ["E2E_READS"] = "4000000"; os.environ["E2E_CPU_READS"] = "1000"
+__file__ = os.path.join(os.getcwd(), "tools", "cli_e2e.py")
+src = open("tools/cli_e2e.py").read().split('run("raw index files')[0]
+exec(src)
+for env in ({"SPUMONI_CACHE": "write"}, {}, {"SPUMONI_WRITE": "pwrite"}, {}, {"SPUMONI_WRITE": "pwrite"}, {}):
+    e = dict(os.environ, **env)
+    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", f"{d}/reads.fa", "-P", "-c", "-n"], capture_output=True, env=e)
+    print(env, r.stderr.decode()[-700:])
+PY
