@@ -1297,7 +1297,7 @@ spx_index* spx_index_load_flat(const char* path, int device) {
         // arrays the kernels then run past
         struct stat stf;
         const uint64_t fsize = fstat(fileno(f), &stf) == 0 ? (uint64_t)stf.st_size : 0;
-        const uint64_t r = h.r;
+        const uint64_t r = h.view.r;  // runs of the flat layout (pieces of long runs count); h.r is the file's r
         const uint64_t row_bytes = h.view.compact ? sizeof(spx::Row32) : sizeof(spx::Row);
         const bool aux = h.has_samples || h.has_docs;
         uint64_t want[spx_index::NARR] = {};
@@ -1311,7 +1311,7 @@ spx_index* spx_index_load_flat(const char* path, int device) {
         want[A_RUNDOCS] = h.has_docs ? (r + ROW_PAD) * 4 : 0;
         want[A_LETTERS] = 256 * sizeof(spx::LetterInfo);
         want[A_TEXT] = h.n_text ? h.n_text + 16 : 0;
-        bool ok = r > 0 && r < 0xfffffff0ull && h.view.r == r && h.n > 0 && h.view.n == h.n &&
+        bool ok = r > 0 && r < 0xfffffff0ull && h.r > 0 && h.r <= r && h.n > 0 && h.view.n == h.n &&
                   h.view.fat_stride == (aux ? 32u : 16u) && (h.n_text == 0 || h.n_text + 1 == h.n || h.n_text < h.n);
         for (int i = 0; ok && i < spx_index::NARR; ++i) {
             ok = h.arr_bytes[i] == want[i];
@@ -1430,11 +1430,11 @@ int spx_index_describe(const spx_index* ix, char* buf, size_t cap) {
     }
     const DevIndex& v = ix->view;
     snprintf(buf, cap,
-             "{\"layout\": \"%s\", \"n\": %llu, \"r\": %llu, \"letters\": %u, \"compact_rows\": %u, "
+             "{\"layout\": \"%s\", \"n\": %llu, \"r\": %llu, \"flat_runs\": %u, \"letters\": %u, \"compact_rows\": %u, "
              "\"fat_slots\": %llu, \"fat_slots_per_run\": %.4f, \"fat_stride\": %u, \"has_samples\": %d, "
              "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu}",
-             SPX_LAYOUT_VERSION, (unsigned long long)ix->n, (unsigned long long)ix->r, v.nletters, v.compact,
-             (unsigned long long)v.nfat, (double)v.nfat / (double)(ix->r ? ix->r : 1), v.fat_stride,
+             SPX_LAYOUT_VERSION, (unsigned long long)ix->n, (unsigned long long)ix->r, v.r, v.nletters, v.compact,
+             (unsigned long long)v.nfat, (double)v.nfat / (double)(v.r ? v.r : 1), v.fat_stride,
              (int)ix->has_samples, (int)ix->has_docs, (unsigned long long)ix->n_text,
              (unsigned long long)(ix->device_bytes + ix->n_text));
     return SPX_OK;

@@ -129,7 +129,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
                              const uint64_t* T, uint64_t nz_total, const uint64_t* ds,
                              const uint64_t* de, const LetterInfo* letters, const uint8_t* Hrun,
                              uint64_t r, uint64_t n, int compact, Row* rows, JumpRow* dirrows, uint32_t* dirdocs,
-                             uint32_t* rundocs, unsigned long long* err) {
+                             uint32_t* rundocs, unsigned long long* err, const uint8_t* cont) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (i >= r) return;
     uint32_t k = Qall[i];
@@ -174,7 +174,7 @@ __global__ void k_build_rows(const uint32_t* Qall, const uint8_t* Hs, const uint
         const Row cr = pack_row_compact(c, (uint32_t)lens[k], (uint32_t)dst, (uint32_t)soff, thr <= S[k], cum);
         Row32* r32 = reinterpret_cast<Row32*>(rows) + k;
         r32->q0 = cr.q0;
-        r32->q1 = cr.q1;
+        r32->q1 = cr.q1 | ((cont && cont[k]) ? CROW_CONT : 0ull);  // a later piece of a long run
     } else {
         rows[k] = pack_row(c, lens[k], (uint32_t)dst, soff, thr <= S[k], S[dst + 1] - S[dst] - soff);
     }
@@ -371,10 +371,133 @@ int build_fat(spx_index* ix) {
     return SPX_OK;
 }
 
+// ---- long runs: pieces (round 3) ---------------------------------------------------------------------------------
+// The compact row encoding (16-bit lengths and offsets; Row32 and k_walk_fast need it) holds runs shorter than 2^16.
+// One longer run used to switch the WHOLE index to the general encoding (939 -> 774 M reads/s on the bench index).
+// Instead such a run is laid out as consecutive PIECES of at most 65 535 positions with the same head.  Nothing the
+// walk computes changes: a step inside a piece is an LF step from that piece's start; a jump to the letter lands on
+// the run's first piece (successor) or its last piece's last position (predecessor) -- the positions the reference
+// computes -- and never consults a later piece's threshold, which is the run's own (at least 1: stored thresholds are
+// non-zero, so the pieces keep thr_bv's rank -> stored-value order intact, thresholds_ds.hpp:484-488) and only matters
+// for a byte >= 128 sitting on the run (Appendix C1), where it compares positions exactly as the reference does.
+// Samples and document ids of every piece are the run's.  Pieces after the first carry the CONT bit in their row: the
+// text rebuild (LF chains from run starts) neither starts nor stops there.  The API still reports the file's r.
+// Not applied (the general encoding is kept) when a letter's non-first run has a zero threshold -- thr_bv then skips
+// stored values and inserted pieces would shift which one a later run reads.
+constexpr uint64_t PIECE_MAX = 65535;
+
+__global__ void k_piece_count(const uint64_t* lens, const uint64_t* thr, uint64_t r, uint32_t* pieces, unsigned long long* zero_thr) {
+    const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (k >= r) return;
+    pieces[k] = (uint32_t)((lens[k] + PIECE_MAX - 1) / PIECE_MAX);
+    if (thr[k] == 0) atomicAdd(zero_thr, 1ull);
+}
+
+__global__ void k_letters_present(const uint8_t* heads, uint64_t r, unsigned int* present) {
+    const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (k >= r) return;
+    const uint32_t h = heads[k] <= 1 ? 1 : heads[k];
+    atomicOr(&present[h >> 5], 1u << (h & 31));
+}
+
+__global__ void k_piece_fill(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr, const uint64_t* ssa,
+                             const uint64_t* esa, const uint64_t* ds, const uint64_t* de, const uint32_t* first_piece, uint64_t r,
+                             uint8_t* heads2, uint64_t* lens2, uint64_t* thr2, uint64_t* ssa2, uint64_t* esa2, uint64_t* ds2,
+                             uint64_t* de2, uint8_t* cont) {
+    const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (k >= r) return;
+    const uint64_t len = lens[k];
+    const uint32_t np = (uint32_t)((len + PIECE_MAX - 1) / PIECE_MAX);
+    uint64_t left = len;
+    for (uint32_t j = 0; j < np; ++j) {
+        const uint64_t o = (uint64_t)first_piece[k] + j;
+        const uint64_t take = left > PIECE_MAX ? PIECE_MAX : left;
+        left -= take;
+        heads2[o] = heads[k];
+        lens2[o] = take;
+        thr2[o] = j == 0 ? thr[k] : (thr[k] ? thr[k] : 1);
+        if (ssa2) ssa2[o] = ssa[k];
+        if (esa2) esa2[o] = esa[k];
+        if (ds2) ds2[o] = ds[k];
+        if (de2) de2[o] = de[k];
+        cont[o] = j ? 1 : 0;
+    }
+}
+
+static int flatten_core(spx_index* ix, uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
+                        const uint64_t* d_ssa, const uint64_t* d_esa, const uint64_t* d_ds, const uint64_t* d_de,
+                        const uint8_t* d_cont);
+
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
                       const uint64_t* d_ds, const uint64_t* d_de) {
     const uint64_t r = ix->r;
+    if (r == 0 || r > 0xfffffff0ull) {
+        set_error("number of runs %llu out of range (1 .. 2^32-16)", (unsigned long long)r);
+        return SPX_E_FORMAT;
+    }
+    hipStream_t st = nullptr;
+    unsigned long long max_len = 0;
+    {
+        DevBuf ml;
+        SPX_HIP(ml.alloc(8));
+        SPX_HIP(hipMemsetAsync(ml.p, 0, 8, st));
+        k_max_len<<<nblocks(r), TPB, 0, st>>>(d_lens, r, ml.as<unsigned long long>());
+        SPX_HIP(hipMemcpyAsync(&max_len, ml.p, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
+    }
+    if (max_len <= PIECE_MAX || getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES"))
+        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
+    // how many pieces, and may the run list be extended at all?
+    DevBuf pieces, first_piece, cnt, present, tmp;
+    SPX_HIP(pieces.alloc((r + 1) * 4));
+    SPX_HIP(first_piece.alloc((r + 1) * 4));
+    SPX_HIP(cnt.alloc(8));
+    SPX_HIP(present.alloc(8 * 4));
+    SPX_HIP(hipMemsetAsync(cnt.p, 0, 8, st));
+    SPX_HIP(hipMemsetAsync(present.p, 0, 32, st));
+    SPX_HIP(hipMemsetAsync(pieces.as<uint32_t>() + r, 0, 4, st));
+    k_piece_count<<<nblocks(r), TPB, 0, st>>>(d_lens, d_thr, r, pieces.as<uint32_t>(), cnt.as<unsigned long long>());
+    k_letters_present<<<nblocks(r), TPB, 0, st>>>(d_heads, r, present.as<unsigned int>());
+    size_t tb = 0;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
+    SPX_HIP(tmp.alloc(tb + 256));
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
+    unsigned long long zero_thr = 0;
+    unsigned int pres[8];
+    uint32_t r2_32 = 0;
+    SPX_HIP(hipMemcpyAsync(&zero_thr, cnt.p, 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(pres, present.p, 32, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&r2_32, first_piece.as<uint32_t>() + r, 4, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    unsigned nletters = 0;
+    for (unsigned v : pres) nletters += (unsigned)__builtin_popcount(v);
+    const uint64_t r2 = r2_32;
+    if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 < r)  // a non-first run with a zero threshold / too many pieces
+        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
+    DevBuf h2, l2, t2, s2, e2, ds2, de2, cont;
+    SPX_HIP(h2.alloc(r2));
+    SPX_HIP(l2.alloc(r2 * 8));
+    SPX_HIP(t2.alloc(r2 * 8));
+    if (d_ssa) SPX_HIP(s2.alloc(r2 * 8));
+    if (d_esa) SPX_HIP(e2.alloc(r2 * 8));
+    if (d_ds) SPX_HIP(ds2.alloc(r2 * 8));
+    if (d_de) SPX_HIP(de2.alloc(r2 * 8));
+    SPX_HIP(cont.alloc(r2));
+    k_piece_fill<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, first_piece.as<uint32_t>(), r,
+                                              h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
+                                              d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr,
+                                              d_de ? de2.as<uint64_t>() : nullptr, cont.as<uint8_t>());
+    SPX_HIP(hipGetLastError());
+    SPX_HIP(hipStreamSynchronize(st));
+    return flatten_core(ix, r2, h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
+                        d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr, d_de ? de2.as<uint64_t>() : nullptr,
+                        cont.as<uint8_t>());
+}
+
+static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
+                        const uint64_t* d_ssa, const uint64_t* d_esa, const uint64_t* d_ds, const uint64_t* d_de,
+                        const uint8_t* d_cont) {
     if (r == 0 || r > 0xfffffff0ull) {
         set_error("number of runs %llu out of range (1 .. 2^32-16)", (unsigned long long)r);
         return SPX_E_FORMAT;
@@ -494,7 +617,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                               T.as<uint64_t>(), nz_total, d_ds, d_de, ix->letters,
                                               H.as<uint8_t>(), r, n, compact, ix->rows, ix->dirrows,
                                               docs ? dirdocs_tmp.as<uint32_t>() : nullptr,
-                                              ix->rundocs, err.as<unsigned long long>());
+                                              ix->rundocs, err.as<unsigned long long>(), compact ? d_cont : nullptr);
     k_sentinel_rows<<<1, 64, 0, st>>>(ix->rows, r, compact);
     if (compact) {
         k_heads_rows<<<nblocks(r + ROW_PAD), TPB, 0, st>>>(ix->rows, H.as<uint8_t>(), r);

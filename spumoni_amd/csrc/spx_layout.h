@@ -45,7 +45,7 @@
 // Names the flat layout AND the walk kernels that read it: a .spx cache written by another layout is
 // refused, and measured HBM traffic (profiles/traffic.json) is only quoted for the version it was
 // taken with.  Bump on any change to a record in this file or to the walk's access pattern.
-#define SPX_LAYOUT_VERSION "spx-flat-r03a"
+#define SPX_LAYOUT_VERSION "spx-flat-r03b"
 
 namespace spx {
 
@@ -105,7 +105,7 @@ SPX_HD Row pack_row_compact(uint32_t H, uint32_t len, uint32_t LFrun, uint32_t L
 // loads): the compact row of run k -- with the heads of the first two runs a step from k can land in -- and,
 // embedded in the same format, the row of the likeliest destination, run D = LFrun:
 //     q0: len[16] | LFoff[16] << 16 | LFrun[32] << 32
-//     q1: H[8] | thr_ok << 8 | hd0[8] << 16 | hd1[8] << 24 | cums << 32      hd_i = head of run LFrun + i
+//     q1: H[8] | thr_ok << 8 | cont << 9 | hd0[8] << 16 | hd1[8] << 24 | cums << 32      hd_i = head of run LFrun + i
 //     e0, e1: q0, q1 of run D (its own hd0 / hd1 included)
 // (hd = 0: past the last run; a head is never 0 after the terminator rewrite.)  A step from (k, off) whose
 // destination is exactly (LFrun, LFoff + off) -- cum0 > off: half of the match steps on the statistical bench
@@ -123,6 +123,10 @@ SPX_HD uint32_t crow_LFrun(const Row& r) { return (uint32_t)(r.q0 >> 32); }
 SPX_HD uint32_t crow_H(const Row& r) { return (uint32_t)r.q1 & 0xff; }
 SPX_HD bool crow_thr_ok(const Row& r) { return (r.q1 >> 8) & 1; }
 SPX_HD uint32_t crow_cums(const Row& r) { return (uint32_t)(r.q1 >> 32); }
+// a later piece of a run of 2^16 positions or more (spx_flatten.hip: such runs are laid out as pieces of the same head):
+// not the first position of a run of the index -- the text rebuild's LF chains neither start nor end there
+constexpr uint64_t CROW_CONT = 1ull << 9;
+SPX_HD bool crow_cont(const Row& r) { return (r.q1 >> 9) & 1; }
 SPX_HD uint32_t crow_dheads(uint64_t q1) { return (uint32_t)(q1 >> 16) & 0xffffu; }  // hd0 | hd1 << 8
 SPX_HD uint64_t crow_with_dheads(uint64_t q1, uint32_t hd0, uint32_t hd1) {
     return (q1 & ~0xffff0000ull) | ((uint64_t)(hd0 & 0xff) << 16) | ((uint64_t)(hd1 & 0xff) << 24);
@@ -249,8 +253,8 @@ struct DevIndex {
     const uint8_t* text;        // MS extension text or nullptr
     uint64_t n_text;
     uint64_t n;
-    uint32_t r;
-    uint32_t compact;   // rows use the compact encoding (every run shorter than 2^16)
+    uint32_t r;         // runs of the flat layout (pieces of long runs count: >= the file's r, spx_index::r)
+    uint32_t compact;   // rows use the compact encoding (every run / piece shorter than 2^16)
     uint32_t nletters;  // byte values that occur in the BWT
     uint64_t nfat;      // fat slots in all (every letter: fat_block(r, bmul) + 2)
     uint32_t init_k;    // run of position n-1  (= r-1)

@@ -1058,6 +1058,7 @@ __global__ void k_text_check(const DevIndex ix, unsigned long long* bad) {
 __global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_text, unsigned long long* stuck) {
     const uint64_t k_start = blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x;
     if (k_start >= ix.r) return;
+    if (ix.compact && crow_cont(row_at(ix, k_start))) return;  // a later piece of a long run: not a run's first position
     uint64_t t = ix.ss_by_run[k_start];
     uint32_t k = (uint32_t)k_start;
     uint64_t off = 0;
@@ -1075,7 +1076,9 @@ __global__ void k_text_from_index(const DevIndex ix, uint8_t* text, uint64_t n_t
             offp -= len;
             k0++;
         }
-        if (offp == 0 || k0 >= ix.r) break;  // the first position of a run: its own lane takes over
+        // the first position of a run: its own lane takes over (the first position of a later PIECE of a long run is
+        // not one: no sample names its text position, the chain goes on through it)
+        if ((offp == 0 && !(ix.compact && crow_cont(row_at(ix, k0)))) || k0 >= ix.r) break;
         if (guard > ix.n) {                  // not a permutation: corrupt run structure
             atomicAdd(stuck, 1ull);
             break;
@@ -1654,14 +1657,14 @@ int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_c
 }
 
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream) {
-    const unsigned grid = (unsigned)((ix->r + WALK_TPB - 1) / WALK_TPB);
+    const unsigned grid = (unsigned)((ix->view.r + WALK_TPB - 1) / WALK_TPB);
     k_text_check<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, d_bad);
     SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
 
 int launch_text_from_index(spx_index* ix, uint8_t* d_text, uint64_t n_text, unsigned long long* d_stuck, hipStream_t stream) {
-    const unsigned grid = (unsigned)((ix->r + WALK_TPB - 1) / WALK_TPB);
+    const unsigned grid = (unsigned)((ix->view.r + WALK_TPB - 1) / WALK_TPB);
     k_text_from_index<<<grid ? grid : 1, WALK_TPB, 0, stream>>>(ix->view, d_text, n_text, d_stuck);
     SPX_HIP(hipGetLastError());
     return SPX_OK;

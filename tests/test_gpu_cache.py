@@ -155,3 +155,36 @@ def test_damaged_cache_header_is_refused(tmp_path):
     open(p, "wb").write(good[: len(good) // 2])  # truncated
     with pytest.raises(capi.SpxError):
         capi.Index.load_flat(p, 0)
+
+
+def test_long_runs_are_laid_out_as_pieces(oracle_mod, tmp_path, monkeypatch):
+    """A run of 2^16 positions or more used to switch the whole index to the general row encoding (17-33 % slower).
+    It is now laid out as pieces of the same head (spx_flatten.hip): compact rows stay, the API reports the file's r,
+    every mode answers like the oracle, the text is rebuilt through the pieces, the cache round-trips -- and
+    SPX_NO_PIECES=1 (the general encoding) gives the same answers."""
+    rng = np.random.default_rng(12)
+    chunks = [rng.choice(np.array(DNA, dtype=np.uint8), size=3000), np.full(150_000, ord("A"), dtype=np.uint8),
+              rng.choice(np.array(DNA, dtype=np.uint8), size=2500), np.full(70_000, 200, dtype=np.uint8),  # a byte >= 128
+              rng.choice(np.array(DNA, dtype=np.uint8), size=2000)]
+    text = np.concatenate(chunks)
+    raw = synth.index_from_text(torch.from_numpy(text.copy()), doc_lengths=[100_000, text.size - 100_000])
+    assert int(raw.lens.max()) >= 65536
+    reads = [text[2000:4500], text[150_000:156_000], np.full(3000, ord("A"), dtype=np.uint8), text[155_000:159_500],
+             np.full(500, 200, dtype=np.uint8), rng.choice(np.array(DNA + [200], dtype=np.uint8), size=800)]
+    offs = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.int64)
+    seqs = np.concatenate(reads)
+    ix = capi.Index.from_raw(raw, 0)
+    d = ix.describe()
+    assert d["compact_rows"] == 1 and d["flat_runs"] > d["r"] == raw.r == ix.r
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
+    ix.rebuild_text()
+    assert np.array_equal(ix.text(), text)
+    p = str(tmp_path / "pieces.spx")
+    ix.save(p)
+    back = capi.Index.load_flat(p, 0)
+    assert back.describe() == d and back.r == raw.r
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=back)
+    monkeypatch.setenv("SPX_NO_PIECES", "1")
+    gen = capi.Index.from_raw(raw, 0)
+    assert gen.describe()["compact_rows"] == 0 and gen.describe()["flat_runs"] == raw.r
+    _compare_all(oracle_mod, raw, text, seqs, offs, ix=gen)
