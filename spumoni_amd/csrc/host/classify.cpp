@@ -531,65 +531,83 @@ void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res,
 
 double g_format_s = 0;  // formatting alone, thread 0's share of every super-batch (for [timing])
 
-// The text came from the device (spx_text.hip): the helper threads drop the ">id\n" lines into their gaps and then
-// format the report lines; the calling thread, once every header is in place, writes each stream with ONE pwrite --
-// writes to one file serialise on its inode lock, so sixteen writers were one writer and fifteen waiters (round 3:
-// 2 GB at 5 GB/s whatever the thread count) -- while the others are busy with the report.
-void write_results_text(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res,
-                        std::vector<TextChunk>& chunks) {
-    const size_t nreads = sb.nreads();
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
-    if (chunks.size() < nt) chunks.resize(nt);
-    OutFile* const files[3] = {&out.lengths, &out.pointers, &out.docs};
+// The text came from the device (spx_text.hip).  Two stages, so that the one thing that cannot be done in parallel --
+// writes to one file serialise on its inode lock: 2 GB go into tmpfs at 5.7 GB/s however many threads call pwrite -- is
+// never waited for by anything else:
+//   begin   helper threads drop the ">id\n" lines into their gaps, then go on to format the report lines of their
+//           ranges; the calling (writer) thread waits for the headers only and writes each stream with ONE pwrite;
+//   finish  (the report thread, one super-batch behind) joins the helpers and appends the report lines.
+struct TextJob {
+    RunOptions ro;
+    size_t nt = 0, nreads = 0;
     std::mutex mu;
     std::condition_variable cv;
     size_t filled = 0;
-    auto lo_of = [&](size_t t) { return nreads * t / nt; };
-    RunOptions ro = o;  // only the report is left to format
-    ro.use_doc = false;
-    ro.ms = false;
-    ro.report_only = true;
-    auto headers = [&](size_t t) {
-        const size_t lo = lo_of(t), hi = lo_of(t + 1);
+    std::vector<std::thread> th;
+    std::vector<TextChunk> chunks;
+};
+
+void write_results_text_begin(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res, TextJob& job) {
+    const size_t nreads = sb.nreads();
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
+    job.nt = nt;
+    job.nreads = nreads;
+    job.filled = 0;
+    if (job.chunks.size() < nt) job.chunks.resize(nt);
+    job.ro = o;  // only the report is left to format
+    job.ro.use_doc = false;
+    job.ro.ms = false;
+    job.ro.report_only = true;
+    OutFile* const files[3] = {&out.lengths, &out.pointers, &out.docs};
+    bool open_[3];
+    for (int i = 0; i < 3; ++i) open_[i] = (res.streams & (1u << i)) && files[i]->is_open();
+    const SuperBatch* psb = &sb;
+    const Results* pres = &res;
+    TextJob* pj = &job;
+    const bool o0 = open_[0], o1 = open_[1], o2 = open_[2];
+    auto helper = [psb, pres, pj, o0, o1, o2](size_t t) {
+        const size_t lo = pj->nreads * t / pj->nt, hi = pj->nreads * (t + 1) / pj->nt;
+        const bool op[3] = {o0, o1, o2};
         for (int i = 0; i < 3; ++i) {
-            if (!(res.streams & (1u << i)) || !files[i]->is_open()) continue;
-            char* base = const_cast<char*>(res.text[i].data());
-            const uint64_t* ls = res.line_start[i].data();
+            if (!op[i]) continue;
+            char* base = const_cast<char*>(pres->text[i].data());
+            const uint64_t* ls = pres->line_start[i].data();
             for (size_t q = lo; q < hi; ++q) {
                 char* p = base + ls[q];
-                const std::string_view id = sb.ids[q];
+                const std::string_view id = psb->ids[q];
                 *p++ = '>';
                 std::memcpy(p, id.data(), id.size());
                 p[id.size()] = '\n';
             }
         }
-        std::lock_guard<std::mutex> g(mu);
-        if (++filled == nt) cv.notify_all();
+        {
+            std::lock_guard<std::mutex> g(pj->mu);
+            if (++pj->filled == pj->nt) pj->cv.notify_all();
+        }
+        format_range(pj->ro, *psb, *pres, lo, hi, pj->chunks[t]);
     };
-    auto helper = [&](size_t t) {
-        headers(t);
-        format_range(ro, sb, res, lo_of(t), lo_of(t + 1), chunks[t]);
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(helper, t);
+    job.th.clear();
+    for (size_t t = 0; t < nt; ++t) job.th.emplace_back(helper, t);
     const auto tf0 = std::chrono::steady_clock::now();
-    headers(0);
     {
-        std::unique_lock<std::mutex> g(mu);
-        cv.wait(g, [&] { return filled == nt; });
+        std::unique_lock<std::mutex> g(job.mu);
+        job.cv.wait(g, [&] { return job.filled == nt; });
     }
     for (int i = 0; i < 3; ++i) {
-        if (!(res.streams & (1u << i)) || !files[i]->is_open()) continue;
+        if (!open_[i]) continue;
         const uint64_t bytes = res.line_start[i][nreads];
         files[i]->write_at(res.text[i].data(), bytes, files[i]->end);
         files[i]->end += bytes;
     }
     g_format_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
-    format_range(ro, sb, res, lo_of(0), lo_of(1), chunks[0]);
-    for (auto& x : th) x.join();
+}
+
+void write_results_text_finish(Outputs& out, const RunOptions& o, TextJob& job) {
+    for (auto& x : job.th) x.join();
+    job.th.clear();
     if (o.write_report)
-        for (size_t t = 0; t < nt; ++t) {
-            const std::string& r = chunks[t].report;
+        for (size_t t = 0; t < job.nt; ++t) {
+            const std::string& r = job.chunks[t].report;
             if (r.empty()) continue;
             out.report.write_at(r.data(), r.size(), out.report.end);
             out.report.end += r.size();
@@ -598,7 +616,12 @@ void write_results_text(Outputs& out, const RunOptions& o, const SuperBatch& sb,
 
 void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res,
                    std::vector<TextChunk>& chunks) {
-    if (res.device_text) return write_results_text(out, o, sb, res, chunks);
+    if (res.device_text) {  // (callers without a report stage: both stages at once)
+        TextJob job;
+        write_results_text_begin(out, o, sb, res, job);
+        write_results_text_finish(out, o, job);
+        return;
+    }
     const size_t nreads = sb.nreads();
     const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
     if (chunks.size() < nt) chunks.resize(nt);
@@ -717,6 +740,7 @@ struct Slot {
     uint64_t seq = 0;            // position of this super-batch in the input (results are written in this order)
     bool last = false;           // no more input after this one
     std::vector<std::vector<ParsedRead>> parsed;  // fill_slot's per-thread reads (kept: their capacity is reused)
+    std::unique_ptr<TextJob> job;  // device text: the helpers of the write in flight (finished by the report thread)
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
 };
@@ -883,7 +907,7 @@ private:
 // (per slot: the reads of a super-batch, and per output stream its text and its record offsets).
 void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
     if (spx_device_count() <= 0) return;
-    const size_t nslots = 2 * std::max<size_t>(ndev, 1) + 2;
+    const size_t nslots = 2 * std::max<size_t>(ndev, 1) + 3;
     const bool report_only = o.report_only && !o.ms && o.write_report;
     const size_t chars = o.super_batch_chars + (4u << 20);
     std::vector<size_t> sizes;
@@ -914,7 +938,8 @@ void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
 size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     Outputs out;
     const size_t max_value_thr = open_outputs_and_threshold(out, o);
-    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_write{"format+write", 0, {}};
+    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_write{"format+write", 0, {}},
+        t_report{"report (one behind)", 0, {}};
     t_load.start();
     // the reads file is mapped and its lines are found while the index loads (spumoni_main.cpp)
     std::unique_ptr<ReadFile> own_input;
@@ -931,7 +956,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     // reference's -t 1 order).  Slots: one being parsed, one per device, one being written, and one
     // more per device so that no device waits for the parser.
     const size_t ndev = set.ix.size();
-    const int NSLOTS = (int)(2 * ndev + 2);
+    const int NSLOTS = (int)(2 * ndev + 3);  // (one more: the report thread holds a slot too)
     // (the slots outlive the call on purpose: unlocking their ~1 GB of page-locked buffers takes a few tenths of a
     // second that the run would spend after its last byte is written; the process ends right after and the
     // operating system takes the pages back)
@@ -969,14 +994,36 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     };
     std::vector<std::thread> workers;
     for (size_t d = 0; d < ndev; ++d) workers.emplace_back(device_worker, d);
+    // writer: the streams, in input order; report thread, one super-batch behind: the report lines, the slot's release
+    // and whatever the reference would have stopped at
+    SlotQueue report_q;
     std::thread writer([&] {
-        std::vector<TextChunk> chunks;  // formatting buffers, kept across super-batches
+        std::vector<TextChunk> chunks;  // formatting buffers of the host-formatted path, kept across super-batches
         for (uint64_t seq = 0;; ++seq) {
             const int i = done.take(seq);
             Slot& s = slots[(size_t)i];
             t_write.start();
-            if (s.sb.nreads() > 0) write_results(out, o, s.sb, s.res, chunks);
+            if (s.sb.nreads() > 0) {
+                if (s.res.device_text) {
+                    if (!s.job) s.job.reset(new TextJob());
+                    write_results_text_begin(out, o, s.sb, s.res, *s.job);
+                } else {
+                    write_results(out, o, s.sb, s.res, chunks);
+                }
+            }
             t_write.stop();
+            const bool last = s.last;
+            report_q.push(i);
+            if (last) break;
+        }
+    });
+    std::thread reporter([&] {
+        for (;;) {
+            const int i = report_q.pop();
+            Slot& s = slots[(size_t)i];
+            t_report.start();
+            if (s.sb.nreads() > 0 && s.res.device_text && s.job) write_results_text_finish(out, o, *s.job);
+            t_report.stop();
             num_reads += s.sb.nreads();
             if (s.deferred == 1) fatal_error("%s", s.deferred_msg.c_str());
             if (s.deferred == 2) {
@@ -1004,10 +1051,11 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
     for (size_t d = 0; d < ndev; ++d) parsed_q.push(-1);
     for (auto& w : workers) w.join();
     writer.join();
+    reporter.join();
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte",
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count());
     // per-stage wall times (ours, additive; stages overlap, so they do not add up to the total)
-    for (StageTimer* t : {&t_load, &t_parse, &t_write})
+    for (StageTimer* t : {&t_load, &t_parse, &t_write, &t_report})
         std::fprintf(stderr, "[timing] %-22s %.3f s\n", t->name, t->total);
     std::fprintf(stderr, "[timing]   segmentation %.3f  parse %.3f  placement %.3f  copy %.3f s\n", g_parse_s[0], g_parse_s[1],
                  g_parse_s[2], g_parse_s[3]);
