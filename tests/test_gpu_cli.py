@@ -231,6 +231,56 @@ def test_end_to_end_from_fasta_with_our_builder(built, tmp_path):
     rep = open(tmp_path / "gpu" / "reads.fa.report").read().splitlines()[1:]
     found = sum("FOUND" in ln and "NOT_PRESENT" not in ln for ln in rep)
     assert 0.3 * len(rep) < found < 0.7 * len(rep)  # sampled reads FOUND, reversed (null) reads not
+    _check_null_databases(tmp_path, prefix, [g1, g2])
+
+
+def _values_file(path):
+    out = []
+    for ln in open(path):
+        if not ln.startswith(">"):
+            out.append(np.array(ln.split(), dtype=np.int64))
+    return out
+
+
+def _check_null_databases(tmp_path, prefix, genomes):
+    """The builder's null reads are the ones src/refbuilder.cpp:83-127 draws (100 per sequence, glibc rand() after srand(0));
+    the databases hold the oracle harness's statistics of those reads reversed (compute_ms_pml.cpp:1409-1506), and the
+    KS threshold is mean + 3 sd of the reads' own windows against the database, MS first (:1549-1663,
+    src/spumoni.cpp:650-694)."""
+    import struct
+    from spumoni_amd import build_index as B
+
+    null_path = os.path.join(os.path.dirname(prefix), "spumoni_null_reads.fa")
+    lines = open(null_path).read().split("\n")
+    names, reads = lines[0:-1:2], lines[1::2]
+    assert names == [f">read_{i}" for i in range(200)] and all(len(r) == 150 for r in reads)
+    g = B.GlibcRand(0)
+    for i, rd in enumerate(reads):
+        gen = genomes[i // 100]
+        at = g.rand() % (gen.size - 150)
+        assert rd == gen[at: at + 150].tobytes().decode(), i
+    d = tmp_path / "nullchk"
+    d.mkdir()
+    with open(d / "rev.fa", "w") as f:
+        for i, rd in enumerate(reads):
+            f.write(f">read_{i}\n{rd[::-1]}\n")
+    per_read = {}
+    for mode, ext in (("M", ".lengths"), ("P", ".pseudo_lengths")):
+        o = subprocess.run([ORC_RUN, prefix, str(d / "rev.fa"), mode, "0", "0", "150", "n", prefix + ".rawtext"], capture_output=True)
+        assert o.returncode == 0, o.stderr.decode()
+        per_read[mode] = _values_file(str(d / "rev.fa") + ext)
+    for mode, ext in (("M", ".msnulldb"), ("P", ".pmlnulldb")):  # the same rand() sequence runs on from the reads through MS into PML
+        vals = np.concatenate(per_read[mode])
+        blob = open(prefix + ext, "rb").read()
+        num, ks, mean, pct = struct.unpack("<Qddd", blob[:32])
+        bits, width = struct.unpack("<QB", blob[32:41])
+        assert num == vals.size == 200 * 150 and bits == num * width and width == B._width(vals.tolist())
+        assert mean == pytest.approx(vals.mean(), rel=1e-12) and pct == B.percentile_value(vals)
+        words = np.frombuffer(blob[41:], dtype="<u8")
+        stored = np.array([(int(words[(i * width) >> 6]) >> ((i * width) & 63) | (int(words[((i * width) >> 6) + 1]) << (64 - ((i * width) & 63)) if ((i * width) & 63) + width > 64 else 0)) & ((1 << width) - 1)
+                           for i in range(num)], dtype=np.int64)
+        assert np.array_equal(stored, vals & ((1 << width) - 1))
+        assert ks == B.ks_threshold(per_read[mode], stored, 150, g) and 0 < ks < 1, ext
 
 
 def test_cli_empty_read_is_fatal_after_earlier_reads_were_written(built, tmp_path):
