@@ -38,9 +38,20 @@ import torch
 from . import capi, synth
 
 
+def _open_maybe_gz(path):
+    """The reference reads its input FASTA files through gzopen (src/refbuilder.cpp:93): plain or gzip-compressed."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    if magic == b"\x1f\x8b":
+        import gzip
+
+        return gzip.open(path, "rb")
+    return open(path, "rb")
+
+
 def read_fasta(path, upper=True):
     seqs, cur = [], []
-    with open(path, "rb") as f:
+    with _open_maybe_gz(path) as f:
         for line in f:
             if line.startswith(b">"):
                 if cur:

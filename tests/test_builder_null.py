@@ -184,3 +184,15 @@ def test_null_db_file_fields_and_width_rule(tmp_path):
     word = struct.unpack("<Q", blob[41:49])[0]
     assert [(word >> (3 * i)) & 7 for i in range(13)] == [v & 7 for v in stats]
     assert B._width([0]) == 1 and B._width([1]) == 1 and B._width([2]) == 1 and B._width([3]) == 2 and B._width([9]) == 4
+
+
+def test_fasta_reader_takes_gzip_like_gzopen(tmp_path):
+    import gzip
+
+    body = b">x some words\nacgt\nAC\n\n>y\nGG\n>empty\n"
+    (tmp_path / "a.fa").write_bytes(body)
+    with gzip.open(tmp_path / "b.fa.gz", "wb") as f:
+        f.write(body)
+    for name in ("a.fa", "b.fa.gz"):
+        assert [s.tobytes() for s in B.read_fasta(str(tmp_path / name))] == [b"ACGTAC", b"GG"]
+        assert [s.tobytes() for s in B.read_fasta(str(tmp_path / name), upper=False)] == [b"acgtAC", b"GG"]
