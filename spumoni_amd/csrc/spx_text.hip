@@ -56,10 +56,10 @@ __global__ void __launch_bounds__(TEXT_TPB) k_text_count(const void* vals, const
         return;
     }
     const uint64_t a = offs[q], b = offs[q + 1];
-    uint32_t sum = 0;
+    uint64_t sum = 0;  // (a read of 2 * 10^8 characters and more has a line of over 2^32 bytes)
     for (uint64_t i = a + lane; i < b; i += 64) sum += dec_width(load_value<T>(vals, i)) + 1;
     for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-    if (lane == 0) line_bytes[q] = (uint64_t)sum + 1 + (gap ? gap[q] : 0);
+    if (lane == 0) line_bytes[q] = sum + 1 + (gap ? gap[q] : 0);
 }
 
 template <class T>

@@ -78,7 +78,12 @@ def test_reads_that_never_jump_fall_back(oracle_mod):
         _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
 
 
-@pytest.mark.parametrize("seed", range(12))
+# (a longer sweep: SPX_FUZZ_FIRST / SPX_FUZZ_SEEDS, as in test_gpu_fuzz.py)
+_FIRST = int(__import__("os").environ.get("SPX_FUZZ_FIRST", "0"))
+_COUNT = int(__import__("os").environ.get("SPX_FUZZ_SEEDS", "12")) if "SPX_FUZZ_FIRST" in __import__("os").environ else 12
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
 def test_chunk_boundary_fuzz(oracle_mod, seed):
     """Random index shapes x chunk sizes x read lengths around multiples of the chunk size."""
     rng = np.random.default_rng(4000 + seed)

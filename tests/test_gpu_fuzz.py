@@ -19,7 +19,11 @@ def gpu():
     return 0
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SPX_FUZZ_SEEDS", "60"))))
+# SPX_FUZZ_SEEDS seeds from SPX_FUZZ_FIRST on (default: 0..59; a longer sweep is a matter of two environment variables)
+_FIRST = int(__import__("os").environ.get("SPX_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(__import__("os").environ.get("SPX_FUZZ_SEEDS", "60"))))
 def test_random_index_shapes(gpu, oracle_mod, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     sigma = int(rng.choice([3, 4, 5, 17, 60, 200]))
