@@ -711,6 +711,20 @@ static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const ui
 // Large host batches: chunks of reads go through copy-in / walk / copy-out on three streams, so the
 // PCIe transfers of one chunk overlap the kernel of another.  Offsets are absolute, so every chunk
 // is launched on the same device buffers with the offsets pointer advanced.  Caller holds host_mu.
+// 16-bit outputs hold values below 65536: a read that long is refused.  first_long_read: its index, or q1 (the error
+// text is thread-local: the caller's thread reports)
+static uint64_t first_long_read(const uint64_t* offsets, uint64_t q0, uint64_t q1) {
+    for (uint64_t q = q0; q < q1; ++q)
+        if (offsets[q + 1] - offsets[q] >= 65536) return q;
+    return q1;
+}
+static int check_narrow_reads(const uint64_t* offsets, uint64_t q0, uint64_t q1) {
+    const uint64_t q = first_long_read(offsets, q0, q1);
+    if (q == q1) return SPX_OK;
+    set_error("read %llu has 65536 characters or more: use the 32-bit entry point", (unsigned long long)q);
+    return SPX_E_ARG;
+}
+
 static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets, uint64_t nreads,
                          uint8_t* d_seq, uint64_t* d_off, uint64_t padded, void* out_lengths, uint64_t* out_pointers,
                          void* out_docs, spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr,
@@ -732,12 +746,29 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         }
     }
     hipStream_t s_in = ix->pipe_s[0], s_k = ix->pipe_s[1], s_out = ix->pipe_s[2];
+    // The pieces GROW.  The call is as long as its copy-out (the results are twice the bytes of the reads, and the
+    // walk is faster than either copy) plus whatever passes before the first result can leave: so the first piece is
+    // small (1/64 of the reads: copied in, walked and on its way out after ~0.4 ms instead of the ~3.7 ms an eighth of
+    // the batch and the whole offsets array took), and every piece is 1.5 x the one before -- less than the 1.7 x by
+    // which the walk outruns the copy-out, so the copy-out stream never waits for a walk.  SPX_PIPE_EVEN=1: equal pieces.
+    uint64_t cut[NCH + 1];
+    {
+        static const bool even = getenv("SPX_PIPE_EVEN") != nullptr;
+        double acc = 0, piece = 1.0 / 64.0;
+        cut[0] = 0;
+        for (int c = 0; c < NCH; ++c) {
+            acc += even ? 1.0 / NCH : piece;
+            piece *= 1.5;
+            // (the series reaches the whole before the last piece: what is left then is one smaller piece)
+            cut[c + 1] = (c + 1 == NCH || acc >= 1.0) ? nreads : (uint64_t)((double)nreads * acc);
+        }
+    }
     if (mode == SPX_MODE_PML && out_lengths) {
         // the length-bit scratch is sized for the largest piece BEFORE the pipeline starts: growing it between
         // pieces would hipFree (an implicit device synchronisation) in the middle of the copy / compute overlap
         uint64_t worst = 0;
         for (int c = 0; c < NCH; ++c) {
-            const uint64_t q0 = nreads * c / NCH, q1 = nreads * (c + 1) / NCH;
+            const uint64_t q0 = cut[c], q1 = cut[c + 1];
             const uint64_t pairs = ((offsets[q1] - offsets[q0]) >> 7) + (q1 - q0) + 2;
             worst = pairs > worst ? pairs : worst;
         }
@@ -747,15 +778,39 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
     if (ix->have_timing && ix->last_stream != s_k) SPX_HIP(hipStreamWaitEvent(s_k, ix->ev_done, 0));
     SPX_HIP(hipMemsetAsync(ix->counters, 0, sizeof(WalkCounters), s_k));
     SPX_HIP(hipEventRecord(ix->ev0, s_k));
-    // offsets and the read-ahead padding first, on the copy-in stream: every chunk's event covers them
-    SPX_HIP(hipMemcpyAsync(d_off, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, s_in));
+    // SPX_PIPE_TRACE=1: when every piece's copy-in, walk and copy-out ended, on stderr (timed events of their own)
+    static const bool trace = getenv("SPX_PIPE_TRACE") != nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
+    hipEvent_t tr0 = nullptr, tr[NCH][3] = {};
+    if (trace) {
+        SPX_HIP(hipEventCreate(&tr0));
+        for (auto& row : tr)
+            for (auto& e : row) SPX_HIP(hipEventCreate(&e));
+        SPX_HIP(hipEventRecord(tr0, s_in));
+    }
+    // 16-bit outputs: the reads' lengths are checked by a thread of its own while this one enqueues (10^7 offsets are
+    // 3-4 ms of one core; in front of the pipeline that is 15 % of the call, and spread between the pieces' enqueues it
+    // made the copy-out of the later pieces slow: profiles/r03_host_path_pipeline.txt)
+    uint64_t long_read = nreads;
+    std::thread narrow_check;
+    if (width == 2) narrow_check = std::thread([&] { long_read = first_long_read(offsets, 0, nreads); });
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{narrow_check};
+    // the read-ahead padding first, on the copy-in stream: every piece's event covers it; a piece's offsets travel
+    // with the piece (the whole array up front is 80 MB for 10^7 reads: 1.4 ms before anything else could start)
     SPX_HIP(hipMemsetAsync(d_seq + total, 0, padded - total, s_in));
     for (int c = 0; c < NCH; ++c) {
-        const uint64_t q0 = nreads * c / NCH, q1 = nreads * (c + 1) / NCH;
+        const uint64_t q0 = cut[c], q1 = cut[c + 1];
         if (q1 == q0) continue;
         const uint64_t a = offsets[q0], b = offsets[q1];
+        SPX_HIP(hipMemcpyAsync(d_off + q0, offsets + q0, (q1 - q0 + 1) * 8, hipMemcpyHostToDevice, s_in));
         SPX_HIP(hipMemcpyAsync(d_seq + a, seqs + a, b - a, hipMemcpyHostToDevice, s_in));
         SPX_HIP(hipEventRecord(ix->pipe_in[c], s_in));
+        if (trace) SPX_HIP(hipEventRecord(tr[c][0], s_in));
         SPX_HIP(hipStreamWaitEvent(s_k, ix->pipe_in[c], 0));
         BatchArgs args{};
         args.seqs = d_seq;
@@ -784,6 +839,7 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
             if ((rc = launch_ms_extend(ix, args, s_k)) != SPX_OK) return rc;
         }
         SPX_HIP(hipEventRecord(ix->pipe_k[c], s_k));
+        if (trace) SPX_HIP(hipEventRecord(tr[c][1], s_k));
         SPX_HIP(hipStreamWaitEvent(s_out, ix->pipe_k[c], 0));
         if (out_lengths)
             SPX_HIP(hipMemcpyAsync((char*)out_lengths + a * width, (char*)dlen + a * width, (b - a) * width,
@@ -796,13 +852,30 @@ static int run_pipelined(spx_index* ix, int mode, const uint8_t* seqs, const uin
         if (out_class)
             SPX_HIP(hipMemcpyAsync(out_class + q0, (spx_class*)dcls + q0, (q1 - q0) * sizeof(spx_class),
                                    hipMemcpyDeviceToHost, s_out));
+        if (trace) SPX_HIP(hipEventRecord(tr[c][2], s_out));
     }
     SPX_HIP(hipEventRecord(ix->ev1, s_k));
     SPX_HIP(hipEventRecord(ix->ev_done, s_k));
     ix->have_timing = true;
     ix->last_stream = s_k;
+    const double h_enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     SPX_HIP(hipStreamSynchronize(s_out));
     SPX_HIP(hipStreamSynchronize(s_k));
+    if (narrow_check.joinable()) narrow_check.join();
+    if (long_read != nreads) return check_narrow_reads(offsets, long_read, nreads);  // (the walk counted it as an error, too)
+    if (trace) {
+        std::fprintf(stderr, "spx pipeline: host: all pieces enqueued after %.2f ms, streams drained after %.2f ms\n", h_enq, 
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
+        std::fprintf(stderr, "spx pipeline: piece reads | copy-in done, walk done, copy-out done (ms after the first copy was enqueued)\n");
+        for (int c = 0; c < NCH; ++c) {
+            float t[3] = {0, 0, 0};
+            if (cut[c + 1] > cut[c])
+                for (int j = 0; j < 3; ++j) (void)hipEventElapsedTime(&t[j], tr0, tr[c][j]);
+            std::fprintf(stderr, "  %2d %9llu | %7.2f %7.2f %7.2f\n", c, (unsigned long long)(cut[c + 1] - cut[c]), t[0], t[1], t[2]);
+            for (auto& e : tr[c]) (void)hipEventDestroy(e);
+        }
+        (void)hipEventDestroy(tr0);
+    }
     WalkCounters wc;
     SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
     if (wc.error) {
@@ -820,13 +893,10 @@ static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const u
     int rc = check_query(ix, mode, seqs, offsets, (uint32_t*)out_lengths, out_pointers, (uint32_t*)out_docs,
                          out_class, bin_width);
     if (rc != SPX_OK) return rc;
-    if (width == 2)
-        for (uint64_t q = 0; q < nreads; ++q)
-            if (offsets[q + 1] - offsets[q] >= 65536) {
-                set_error("read %llu has 65536 characters or more: use the 32-bit entry point",
-                          (unsigned long long)q);
-                return SPX_E_ARG;
-            }
+    // (a pipelined batch checks its pieces as it enqueues them: 10^7 offsets are 3 ms of one core, spent beside the
+    // device's work there instead of in front of it)
+    const bool pipelined = nreads >= (1ull << 18) && nreads && offsets[nreads] >= (64u << 20);
+    if (width == 2 && !pipelined && (rc = check_narrow_reads(offsets, 0, nreads)) != SPX_OK) return rc;
     std::lock_guard<std::mutex> hg(ix->host_mu);  // one host-buffer query at a time per index
     SPX_HIP(hipSetDevice(ix->device));
     const uint64_t total = nreads ? offsets[nreads] : 0;
@@ -834,7 +904,7 @@ static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const u
     const uint64_t padded = ((total + 3) / 4) * 4 + 32;
     if ((rc = ensure_scratch(ix, 0, padded, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
-    if (nreads >= (uint64_t)spx_index::PIPE_CHUNKS * 32768 && total >= (64u << 20))
+    if (pipelined)
         return run_pipelined(ix, mode, seqs, offsets, nreads, (uint8_t*)dseq, (uint64_t*)doff, padded, out_lengths,
                              out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
     SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));

@@ -157,7 +157,7 @@ struct spx_index {
     char source_tag[128] = {0};          // spx_index_set_source_tag(): the caller's fingerprint of the index files
     // host-buffer queries of large batches run as a pipeline over chunks of reads: copy in,
     // walk, copy out on three streams (created on first use)
-    static constexpr int PIPE_CHUNKS = 8;
+    static constexpr int PIPE_CHUNKS = 10;  // pieces of a pipelined host batch (growing: run_pipelined)
     hipStream_t pipe_s[3] = {nullptr, nullptr, nullptr};
     hipEvent_t pipe_in[PIPE_CHUNKS] = {}, pipe_k[PIPE_CHUNKS] = {};
     std::mutex mu;       // device-buffer queries / options

@@ -143,7 +143,7 @@ def test_automatic_choice_and_device_entry_point(oracle_mod):
 
 
 def test_pipelined_host_batch_pieces_take_the_chunked_walk(oracle_mod):
-    """A host batch of >= 2^18 reads and >= 64 MB runs as a pipeline of eight pieces whose offsets stay absolute: every
+    """A host batch of >= 2^18 reads and >= 64 MB runs as a pipeline of (growing) pieces whose offsets stay absolute: every
     piece takes the chunked walk with its scratch (flags, checkpoints) indexed from the piece's first character.  Same
     values as the plain walk of the whole batch, and as the oracle on a sample."""
     raw = synth.statistical_rlbwt(1 << 18, 60, 6.0, seed=8, device="cuda", zipf=1.0, with_samples=True, n_docs=7)

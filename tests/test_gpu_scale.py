@@ -147,6 +147,30 @@ def test_host_entry_points_pipeline_large_batches(oracle_mod):
     assert np.array_equal(ref_ms["docs"][: offs[ns]], w["docs"])
 
 
+def test_pipelined_16_bit_batch_with_a_read_too_long_is_refused():
+    """The 16-bit host entry point on a pipelined batch (>= 2^18 reads, >= 64 MB): the reads' lengths are checked beside
+    the pipeline, not in front of it -- a read of 65536 characters or more still fails the call with the same error
+    (and the 32-bit entry point takes the batch)."""
+    raw, text = cases.real_case(19, 50_000, list(b"ACGT"))
+    ix = capi.Index.from_raw(raw, 0)
+    rng = np.random.default_rng(6)
+    nreads = (1 << 18) + 3
+    lens = np.full(nreads, 260, dtype=np.int64)
+    lens[nreads - 7] = 70_000
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seqs = text[rng.integers(0, text.size, size=int(offs[-1]))]
+    assert seqs.size >= (64 << 20)
+    with pytest.raises(capi.SpxError, match=f"read {nreads - 7} has 65536 characters or more"):
+        ix.query_host(capi.SPX_MODE_PML, seqs, offs, bits=16)
+    got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, bits=32)
+    lens[nreads - 7] = 260  # without the long read the 16-bit call goes through, same values for the reads before it
+    offs2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cut = int(offs[nreads - 7])
+    seqs2 = np.concatenate([seqs[:cut], seqs[cut: cut + 260], seqs[int(offs[nreads - 6]):]])
+    got16 = ix.query_host(capi.SPX_MODE_PML, seqs2, offs2, bits=16)
+    assert np.array_equal(got16["lengths"][:cut], got["lengths"][:cut])
+
+
 def test_config4_scale_ms_doc(oracle_mod):
     """BASELINE config[3] shape at scale: statistical index r = 2^27 with SA samples and 10 documents, 5 * 10^6
     reads of 55 minimizer characters, MS pointers + document ids (MS lengths need a text, which a statistical
