@@ -132,3 +132,47 @@ print(f"S2 32B rows, embed best: row {row2b / steps:.3f} + fat {fat / steps:.3f}
 row2n = sim_s2(emb0, heads_known=False)
 print(f"S2 32B rows, embed t=0, NO destination heads: row {row2n / steps:.3f} + fat {fat / steps:.3f} = {(row2n + fat) / steps:.3f} gathers/char, "
       f"lane loads {(2 * row2n + fat) / steps:.3f}")
+
+
+# --- S3: wider rows that embed the lite rows of TWO destinations (t = 0 and t = 1), heads of the others
+def sim_s3(ts=(0, 1)):
+    full = np.ones(nreads, bool)
+    rowg = 0
+    for i in range(m - 1):
+        Mi, Ti, k0i, runi = rec[i]
+        nm = rec[i + 1][0]
+        emb = Mi & full & np.isin(Ti, ts)
+        need = Mi & ~emb & (nm | (~nm & (Ti >= 4)))
+        needj = ~Mi & nm
+        g = need | needj
+        rowg += g.sum()
+        full = g
+    return rowg
+
+
+# --- S4: 64-byte rows that embed destination t = 0 WITH that row's own embedded destination (a chain of two):
+# up to three LF steps per gather
+def sim_s4():
+    depth = np.full(nreads, 2)  # embedded levels still available below the row the lane stands on
+    rowg = 0
+    for i in range(m - 1):
+        Mi, Ti, k0i, runi = rec[i]
+        nm = rec[i + 1][0]
+        emb = Mi & (depth > 0) & (Ti == 0)
+        need = Mi & ~emb & (nm | (~nm & (Ti >= 4)))
+        needj = ~Mi & nm
+        g = need | needj
+        rowg += g.sum()
+        depth = np.where(g, 2, np.where(emb, depth - 1, 0))
+    return rowg
+
+
+row3 = sim_s3()
+print(f"S3 48B rows, embed t=0 and t=1: row {row3 / steps:.3f} + fat {fat / steps:.3f} = {(row3 + fat) / steps:.3f} gathers/char, "
+      f"lane loads {(3 * row3 + fat) / steps:.3f}")
+row3b = sim_s3((0, 1, 2))
+print(f"S3' 64B rows, embed t=0,1,2  : row {row3b / steps:.3f} + fat {fat / steps:.3f} = {(row3b + fat) / steps:.3f} gathers/char, "
+      f"lane loads {(4 * row3b + fat) / steps:.3f}")
+row4 = sim_s4()
+print(f"S4 48B rows, chain of two t=0 : row {row4 / steps:.3f} + fat {fat / steps:.3f} = {(row4 + fat) / steps:.3f} gathers/char, "
+      f"lane loads {(3 * row4 + fat) / steps:.3f}")
