@@ -263,7 +263,7 @@ __global__ void k_fill_cnt(const uint32_t* Qall, const LetterInfo* letters, cons
 // blockIdx.y walks the letters that occur (lets[]), blockIdx.x strides over the letter's slots.
 __global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Aux* aux, const uint32_t* Qall,
                            const LetterInfo* letters, const uint8_t* lets, uint64_t r, char* fat, uint32_t stride,
-                           int force_esc) {
+                           int force_esc, const Row* rows, int compact) {
     const LetterInfo li = letters[lets[blockIdx.y]];
     const uint64_t nblk = (uint64_t)fat_block((uint32_t)r, li.bmul) + 2;
     for (uint64_t b = blockIdx.x * (uint64_t)TPB + threadIdx.x; b < nblk; b += (uint64_t)gridDim.x * TPB) {
@@ -273,7 +273,16 @@ __global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Au
         bool single = false;
         if (j < li.qend && fat_block(Qall[j], li.bmul) == b)
             single = (j + 1 >= li.qend) || fat_block(Qall[j + 1], li.bmul) > b;
-        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(dirrows[j], j >= li.qend, j <= li.qbeg, force_esc != 0, single);
+        // Hp: the head of the run a predecessor jump lands in when that is not the successor's landing run
+        const JumpRow jr = dirrows[j];
+        const uint32_t srun = jr_sLFrun(jr);
+        uint32_t Hp = 0;
+        if (!jr_psame(jr) && srun > 0 && srun <= r) {
+            const Row& pr = *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) +
+                                                           (uint64_t)(srun - 1) * (compact ? sizeof(Row32) : sizeof(Row)));
+            Hp = compact ? crow_H(pr) : row_H(pr);
+        }
+        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(jr, j >= li.qend, j <= li.qbeg, force_esc != 0, single, Hp);
         if (aux) *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
     }
 }
@@ -361,7 +370,7 @@ int build_fat(spx_index* ix) {
     const unsigned gx = most_slots / TPB + 1 < (1u << 20) ? (unsigned)(most_slots / TPB + 1) : (1u << 20);
     k_fill_fat<<<dim3(gx, (unsigned)lets.size()), TPB, 0, st>>>(ix->fat_j, ix->dirrows, ix->aux, Qall, ix->letters,
                                                                  dl.as<uint8_t>(), r, ix->fat, fat_stride,
-                                                                 getenv("SPX_FAT_ALL_ESC") ? 1 : 0);
+                                                                 getenv("SPX_FAT_ALL_ESC") ? 1 : 0, ix->rows, (int)ix->view.compact);
     SPX_HIP(hipGetLastError());
     SPX_HIP(hipStreamSynchronize(st));
     if (timing) fprintf(stderr, "[spx] build_fat: k_fill_fat %.3f s\n", now() - t0);
@@ -732,6 +741,7 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     ix->view.nfat = nfat;
     ix->view.fat_stride = fat_stride;
     ix->view.r = (uint32_t)r;
+    ix->view.compact = (uint32_t)compact;  // (build_fat reads the heads of landing runs out of the rows)
     {
         const int rc_fat = build_fat(ix);
         if (rc_fat != SPX_OK) return rc_fat;

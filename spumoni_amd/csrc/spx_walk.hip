@@ -404,7 +404,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 const uint32_t srun = (uint32_t)(w0 >> 32);
                 g0 = (uint64_t)hq | ((uint64_t)(hq - (uint32_t)(w1 & 0x7ffff)) << 32);
                 g1 = ((w1 >> 20) & 0xffff) | ((uint64_t)(srun & 0xffffff) << 40);
-                g2 = ((w1 >> 36) & 0xffff) | ((uint64_t)(srun >> 24) << 40) | (((w1 >> 60) & 1) << 48) |
+                // (the sLFoff field holds the offset only when psame; otherwise Hp, which this body does not use)
+                g2 = (((w1 >> 60) & 1) ? ((w1 >> 36) & 0xffff) : 0ull) | ((uint64_t)(srun >> 24) << 40) | (((w1 >> 60) & 1) << 48) |
                      (((w1 >> 52) & 0xff) << 49);
                 jdir = nosucc ? qend : (((w1 >> 63) & 1) ? qbeg : qbeg + 1);
                 do_decide = true;
