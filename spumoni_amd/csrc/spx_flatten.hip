@@ -393,13 +393,44 @@ int build_fat(spx_index* ix) {
 // text rebuild (LF chains from run starts) neither starts nor stops there.  The API still reports the file's r.
 // Not applied (the general encoding is kept) when a letter's non-first run has a zero threshold -- thr_bv then skips
 // stored values and inserted pieces would shift which one a later run reads.
-constexpr uint64_t PIECE_MAX = 65535;
+// Balanced pieces (round 3, late): a piece also ends where its LF image has covered `span` runs (spx_layout.h:
+// for_each_piece), so that a step is never more than span - 4 rows away from the row the compact encoding sends it to
+// (tools/ff_model.py; tests/piece_cuts_check.cpp holds the cut rule against its specification on the CPU).  The images
+// are known after a pass of their own over the run list (S, the heads' order, LF of every run start): it is made for an
+// index whose longest run has SPX_BALANCE_MIN_RUN (2048) positions or more -- an image covers no more runs than the run
+// has positions -- and cuts where an image covers more than SPX_BALANCE_SPAN (16; 0: never) runs.  One pass: the new
+// pieces are run boundaries themselves and may push another image past the bound again, by as many as were added inside it.
 
-__global__ void k_piece_count(const uint64_t* lens, const uint64_t* thr, uint64_t r, uint32_t* pieces, unsigned long long* zero_thr) {
+__global__ void k_scatter_u64(const uint64_t* src, const uint32_t* idx, uint64_t r, uint64_t* dst) {
+    uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
+    if (i < r) dst[idx[i]] = src[i];
+}
+
+struct PieceCounter {
+    SPX_HD void operator()(uint64_t, uint64_t) const {}
+};
+
+// image of run k: a = run that holds LF(S[k]), nb = run starts inside the image (0 when the pass was not made)
+__device__ __forceinline__ void image_of(const uint64_t* S, const uint64_t* LFk, uint64_t r, uint64_t k, uint64_t len, uint64_t& lf,
+                                         uint64_t& a, uint64_t& nb) {
+    lf = 0;
+    a = 0;
+    nb = 0;
+    if (!S || len == 0 || len > MASK40) return;
+    lf = LFk[k];
+    a = run_of_position(S, r, lf);
+    nb = run_of_position(S, r, lf + len - 1) - a;
+}
+
+__global__ void k_piece_count(const uint64_t* lens, const uint64_t* thr, uint64_t r, const uint64_t* S, const uint64_t* LFk,
+                              uint32_t span, uint32_t* pieces, unsigned long long* zero_thr, unsigned long long* span_max) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (k >= r) return;
-    pieces[k] = (uint32_t)((lens[k] + PIECE_MAX - 1) / PIECE_MAX);
+    uint64_t lf, a, nb;
+    image_of(S, LFk, r, k, lens[k], lf, a, nb);
+    pieces[k] = for_each_piece(lens[k], lf, S, a, nb, span, PieceCounter{});
     if (thr[k] == 0) atomicAdd(zero_thr, 1ull);
+    if (S && nb + 1 > span) atomicMax(span_max, (unsigned long long)(nb + 1));
 }
 
 __global__ void k_letters_present(const uint8_t* heads, uint64_t r, unsigned int* present) {
@@ -409,28 +440,40 @@ __global__ void k_letters_present(const uint8_t* heads, uint64_t r, unsigned int
     atomicOr(&present[h >> 5], 1u << (h & 31));
 }
 
+struct PieceWriter {
+    uint8_t head;
+    uint64_t thr, ssa, esa, ds, de;
+    uint64_t o;  // where the next piece goes
+    bool first;
+    uint8_t* heads2;
+    uint64_t *lens2, *thr2, *ssa2, *esa2, *ds2, *de2;
+    uint8_t* cont;
+    SPX_HD void operator()(uint64_t, uint64_t plen) {
+        heads2[o] = head;
+        lens2[o] = plen;
+        thr2[o] = first ? thr : (thr ? thr : 1);
+        if (ssa2) ssa2[o] = ssa;
+        if (esa2) esa2[o] = esa;
+        if (ds2) ds2[o] = ds;
+        if (de2) de2[o] = de;
+        cont[o] = first ? 0 : 1;
+        first = false;
+        ++o;
+    }
+};
+
 __global__ void k_piece_fill(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr, const uint64_t* ssa,
                              const uint64_t* esa, const uint64_t* ds, const uint64_t* de, const uint32_t* first_piece, uint64_t r,
+                             const uint64_t* S, const uint64_t* LFk, uint32_t span,
                              uint8_t* heads2, uint64_t* lens2, uint64_t* thr2, uint64_t* ssa2, uint64_t* esa2, uint64_t* ds2,
                              uint64_t* de2, uint8_t* cont) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (k >= r) return;
-    const uint64_t len = lens[k];
-    const uint32_t np = (uint32_t)((len + PIECE_MAX - 1) / PIECE_MAX);
-    uint64_t left = len;
-    for (uint32_t j = 0; j < np; ++j) {
-        const uint64_t o = (uint64_t)first_piece[k] + j;
-        const uint64_t take = left > PIECE_MAX ? PIECE_MAX : left;
-        left -= take;
-        heads2[o] = heads[k];
-        lens2[o] = take;
-        thr2[o] = j == 0 ? thr[k] : (thr[k] ? thr[k] : 1);
-        if (ssa2) ssa2[o] = ssa[k];
-        if (esa2) esa2[o] = esa[k];
-        if (ds2) ds2[o] = ds[k];
-        if (de2) de2[o] = de[k];
-        cont[o] = j ? 1 : 0;
-    }
+    uint64_t lf, a, nb;
+    image_of(S, LFk, r, k, lens[k], lf, a, nb);
+    PieceWriter w{heads[k], thr[k], ssa2 ? ssa[k] : 0, esa2 ? esa[k] : 0, ds2 ? ds[k] : 0, de2 ? de[k] : 0,
+                  first_piece[k], true, heads2, lens2, thr2, ssa2, esa2, ds2, de2, cont};
+    for_each_piece(lens[k], lf, S, a, nb, span, w);
 }
 
 static int flatten_core(spx_index* ix, uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
@@ -455,34 +498,98 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(hipMemcpyAsync(&max_len, ml.p, 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipStreamSynchronize(st));
     }
-    if (max_len <= PIECE_MAX || getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES"))
+    uint32_t span = 16;
+    uint64_t min_run = 2048;
+    if (const char* e = getenv("SPX_BALANCE_SPAN")) span = (uint32_t)atoi(e);
+    if (const char* e = getenv("SPX_BALANCE_MIN_RUN")) min_run = (uint64_t)atoll(e);
+    bool balance = span > 0 && max_len >= min_run && max_len <= MASK40;
+    if (getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES") || (max_len <= PIECE_MAX && !balance))
         return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
+    const bool timing = getenv("SPX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_bal = now();
+    // the images: S (run starts) and LF of every run start, by run (the arrays flatten_core builds again for the
+    // pieces: this pass is only made for an index with a long run)
+    DevBuf Sb, LFk;
+    if (balance) {
+        DevBuf H, iota, Hs, Qall, ls, LFs, tmp, err;
+        SPX_HIP(H.alloc(r));
+        SPX_HIP(iota.alloc(r * 4));
+        SPX_HIP(Hs.alloc(r));
+        SPX_HIP(Qall.alloc(r * 4));
+        SPX_HIP(Sb.alloc((r + 1) * 8));
+        SPX_HIP(err.alloc(8));
+        SPX_HIP(hipMemsetAsync(err.p, 0, 8, st));
+        k_norm_heads<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, r, H.as<uint8_t>(), iota.as<uint32_t>(), err.as<unsigned long long>());
+        size_t tb = 0, tb2 = 0;
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_lens, Sb.as<uint64_t>(), r, st));
+        SPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
+                                                   Qall.as<uint32_t>(), r, 0, 8, st));
+        if (tb2 > tb) tb = tb2;
+        SPX_HIP(tmp.alloc(tb + 256));
+        size_t tbs = tb;
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, d_lens, Sb.as<uint64_t>(), r, st));
+        uint64_t last_s = 0, last_len = 0;
+        unsigned long long bad = 0;
+        SPX_HIP(hipMemcpyAsync(&last_s, Sb.as<uint64_t>() + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&last_len, d_lens + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&bad, err.p, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
+        const uint64_t n = last_s + last_len;
+        if (bad || n > MASK40 - 2) {
+            balance = false;  // (a run of length 0 / a BWT too long: flatten_core says so)
+        } else {
+            SPX_HIP(hipMemcpyAsync(Sb.as<uint64_t>() + r, &n, 8, hipMemcpyHostToDevice, st));
+            tbs = tb;
+            SPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbs, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
+                                                       Qall.as<uint32_t>(), r, 0, 8, st));
+            SPX_HIP(ls.alloc(r * 8));
+            SPX_HIP(LFs.alloc((r + 1) * 8));
+            SPX_HIP(LFk.alloc(r * 8));
+            k_gather_u64<<<nblocks(r), TPB, 0, st>>>(d_lens, Qall.as<uint32_t>(), r, ls.as<uint64_t>());
+            tbs = tb;
+            SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, ls.as<uint64_t>(), LFs.as<uint64_t>(), r, st));
+            k_scatter_u64<<<nblocks(r), TPB, 0, st>>>(LFs.as<uint64_t>(), Qall.as<uint32_t>(), r, LFk.as<uint64_t>());
+            SPX_HIP(hipGetLastError());
+            SPX_HIP(hipStreamSynchronize(st));
+        }
+    }
+    if (!balance && max_len <= PIECE_MAX)
+        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
+    const uint64_t* d_S = balance ? Sb.as<uint64_t>() : nullptr;
+    const uint64_t* d_LFk = balance ? LFk.as<uint64_t>() : nullptr;
+    if (!balance) span = 0;
     // how many pieces, and may the run list be extended at all?
     DevBuf pieces, first_piece, cnt, present, tmp;
     SPX_HIP(pieces.alloc((r + 1) * 4));
     SPX_HIP(first_piece.alloc((r + 1) * 4));
-    SPX_HIP(cnt.alloc(8));
+    SPX_HIP(cnt.alloc(16));
     SPX_HIP(present.alloc(8 * 4));
-    SPX_HIP(hipMemsetAsync(cnt.p, 0, 8, st));
+    SPX_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
     SPX_HIP(hipMemsetAsync(present.p, 0, 32, st));
     SPX_HIP(hipMemsetAsync(pieces.as<uint32_t>() + r, 0, 4, st));
-    k_piece_count<<<nblocks(r), TPB, 0, st>>>(d_lens, d_thr, r, pieces.as<uint32_t>(), cnt.as<unsigned long long>());
+    k_piece_count<<<nblocks(r), TPB, 0, st>>>(d_lens, d_thr, r, d_S, d_LFk, span, pieces.as<uint32_t>(), cnt.as<unsigned long long>(),
+                                               cnt.as<unsigned long long>() + 1);
     k_letters_present<<<nblocks(r), TPB, 0, st>>>(d_heads, r, present.as<unsigned int>());
     size_t tb = 0;
     SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
     SPX_HIP(tmp.alloc(tb + 256));
     SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
-    unsigned long long zero_thr = 0;
+    unsigned long long zero_thr = 0, span_max = 0;
     unsigned int pres[8];
     uint32_t r2_32 = 0;
     SPX_HIP(hipMemcpyAsync(&zero_thr, cnt.p, 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&span_max, cnt.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipMemcpyAsync(pres, present.p, 32, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipMemcpyAsync(&r2_32, first_piece.as<uint32_t>() + r, 4, hipMemcpyDeviceToHost, st));
     SPX_HIP(hipStreamSynchronize(st));
     unsigned nletters = 0;
     for (unsigned v : pres) nletters += (unsigned)__builtin_popcount(v);
     const uint64_t r2 = r2_32;
-    if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 < r)  // a non-first run with a zero threshold / too many pieces
+    if (timing)
+        fprintf(stderr, "[spx] pieces: %llu runs -> %llu rows%s; longest image %llu runs (0: none over %u), longest run %llu; %.3f s\n",
+                (unsigned long long)r, (unsigned long long)r2, balance ? " (balanced)" : "", span_max, span, max_len, now() - t_bal);
+    if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 <= r)  // a non-first run with a zero threshold / too many pieces / none
         return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
     DevBuf h2, l2, t2, s2, e2, ds2, de2, cont;
     SPX_HIP(h2.alloc(r2));
@@ -494,11 +601,16 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     if (d_de) SPX_HIP(de2.alloc(r2 * 8));
     SPX_HIP(cont.alloc(r2));
     k_piece_fill<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, first_piece.as<uint32_t>(), r,
-                                              h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
+                                              d_S, d_LFk, span, h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
                                               d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr,
                                               d_de ? de2.as<uint64_t>() : nullptr, cont.as<uint8_t>());
     SPX_HIP(hipGetLastError());
     SPX_HIP(hipStreamSynchronize(st));
+    // (the table below sizes itself against the memory that is free: nothing of this function's own stays allocated)
+    for (DevBuf* b : {&Sb, &LFk, &pieces, &first_piece, &tmp, &cnt, &present}) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+    }
     return flatten_core(ix, r2, h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
                         d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr, d_de ? de2.as<uint64_t>() : nullptr,
                         cont.as<uint8_t>());

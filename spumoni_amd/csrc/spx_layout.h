@@ -275,4 +275,52 @@ SPX_HD const Row& row_at(const DevIndex& ix, uint64_t k) {
     return *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(ix.rows) + k * (ix.compact ? sizeof(Row32) : sizeof(Row)));
 }
 
+// ---- pieces of a run (spx_flatten.hip) -----------------------------------------------------------------------------
+// A run is laid out as consecutive PIECES of the same head when (a) it holds 2^16 positions or more (the compact row's
+// 16-bit fields), or (b) its LF image covers many runs: a step out of offset `off` of run k lands LF(S[k]) + off, in run
+// LFrun + t, and the compact row answers t < 4 outright; past that the walk moves on one row -- one dependent gather --
+// at a time.  That is 0.02 gathers per character on the bench index and unbounded in principle (the move structure's
+// known worst case: a long run whose image covers thousands of short ones; tools/ff_model.py: 141 gathers per step on
+// Pareto-distributed run lengths).  So a piece also ends where its image has covered `span` runs (balancing in the
+// sense of Nishimoto & Tabei, one pass): at most span - 4 rows are walked on from any landing, for at most r / span * 2
+// more rows.
+constexpr uint64_t PIECE_MAX = 65535;
+
+// run of position p: the largest k in [0, r) with S[k] <= p  (S[0] = 0, ascending, S[r] = n)
+SPX_HD uint64_t run_of_position(const uint64_t* S, uint64_t r, uint64_t p) {
+    uint64_t lo = 0, hi = r;  // S[lo] <= p < S[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (S[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// f(offset, length) for every piece of a run of `len` positions, in order; returns how many.
+// S == nullptr or span == 0: pieces of PIECE_MAX positions only.  Otherwise lf = LF(start of the run), a = the run that
+// holds position lf, nb = how many run starts S[a + 1 .. a + nb] lie inside the image (lf, lf + len).
+template <class F>
+SPX_HD uint32_t for_each_piece(uint64_t len, uint64_t lf, const uint64_t* S, uint64_t a, uint64_t nb, uint32_t span, F&& f) {
+    uint32_t np = 0;
+    uint64_t pos = 0, i = 1;  // S[a + i] - lf: the first run start inside the image that lies after pos
+    const bool balance = S != nullptr && span > 0;
+    do {
+        uint64_t next = len - pos > PIECE_MAX ? pos + PIECE_MAX : len;
+        if (balance && i + span - 1 <= nb) {
+            // [pos, cand) covers the runs a + i - 1 .. a + i + span - 2: `span` of them
+            const uint64_t cand = S[a + i + span - 1] - lf;
+            if (cand < next) next = cand;
+        }
+        f(pos, next - pos);
+        ++np;
+        pos = next;
+        if (balance)
+            while (i <= nb && S[a + i] - lf <= pos) ++i;  // (at most `span` steps: the piece covers no more runs)
+    } while (pos < len);
+    return np;
+}
+
 }  // namespace spx

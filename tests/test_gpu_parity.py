@@ -356,6 +356,34 @@ def test_long_runs_and_far_thresholds(gpu, oracle_mod):
         _compare_all(oracle_mod, raw, None, seqs, offs.cpu().numpy())
 
 
+def test_balanced_pieces_bound_the_walk_past_the_landing_row(gpu, oracle_mod, monkeypatch):
+    """Heavy-tailed run lengths (Pareto, longest run 7871 among runs of 1-2): the LF image of a long run covers up to
+    1393 runs, and a step out of it walks on row by row from the fifth (42 gathers per step for positions drawn
+    uniformly, tools/ff_model.py).  The flatten step cuts such runs into pieces whose images cover at most 16 runs
+    (spx_layout.h: for_each_piece): 2 % more rows, the same answers in every mode, and a fraction of the row gathers;
+    SPX_BALANCE_SPAN=0 is the layout without it."""
+    rng = np.random.default_rng(8)
+    r = 1 << 16
+    idx = np.cumsum(rng.integers(1, 4, size=r)) % 4
+    lens = np.minimum((rng.pareto(1.2, size=r) + 1).astype(np.int64), 1 << 18)
+    heads = np.frombuffer(b"ACGT", dtype=np.uint8)[idx].copy()
+    heads[r // 2], lens[r // 2] = 0, 1
+    assert 2048 <= lens.max() < 65536  # (no piece is cut for its length here)
+    raw = synth.raw_from_runs(torch.from_numpy(heads), torch.from_numpy(lens), 4, with_samples=True, n_docs=3)
+    seqs, offs = synth.simulate_reads(raw, 3000, 80, seed=2, positive_fraction=0.7)
+    s, o = seqs.cpu().numpy(), offs.cpu().numpy()
+    ix, st = _compare_all(oracle_mod, raw, None, s, o)
+    d = ix.describe()
+    monkeypatch.setenv("SPX_BALANCE_SPAN", "0")
+    ix0 = capi.Index.from_raw(raw, 0)
+    _, st0 = _compare_all(oracle_mod, raw, None, s, o, ix=ix0)
+    d0 = ix0.describe()
+    assert d["r"] == d0["r"] == raw.r == d0["flat_runs"] and d["compact_rows"] == d0["compact_rows"] == 1
+    assert d0["flat_runs"] < d["flat_runs"] <= d0["flat_runs"] + raw.r // 8
+    assert (st["steps"], st["jumps"]) == (st0["steps"], st0["jumps"])
+    assert 3 * st["row_loads"] < st0["row_loads"], (st, st0)
+
+
 def test_16_bit_outputs_refuse_long_reads(gpu):
     raw, text = cases.real_case(3, 400, DNA)
     ix = capi.Index.from_raw(raw, 0)
