@@ -398,8 +398,9 @@ int build_fat(spx_index* ix) {
 // (tools/ff_model.py; tests/piece_cuts_check.cpp holds the cut rule against its specification on the CPU).  The images
 // are known after a pass of their own over the run list (S, the heads' order, LF of every run start): it is made for an
 // index whose longest run has SPX_BALANCE_MIN_RUN (2048) positions or more -- an image covers no more runs than the run
-// has positions -- and cuts where an image covers more than SPX_BALANCE_SPAN (16; 0: never) runs.  One pass: the new
-// pieces are run boundaries themselves and may push another image past the bound again, by as many as were added inside it.
+// has positions -- and cuts where an image covers more than SPX_BALANCE_SPAN (8; 0: never) runs.  The new pieces are run
+// boundaries themselves and may push another image past the bound again, so the pass is repeated on its own output until
+// nothing is cut or SPX_BALANCE_PASSES (4) were made (the fourth cuts a few rows in 10^4: profiles/r03_balanced_pieces_passes.txt).
 
 __global__ void k_scatter_u64(const uint64_t* src, const uint32_t* idx, uint64_t r, uint64_t* dst) {
     uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x;
@@ -445,6 +446,7 @@ struct PieceWriter {
     uint64_t thr, ssa, esa, ds, de;
     uint64_t o;  // where the next piece goes
     bool first;
+    uint8_t cont0;  // the run is itself a later piece of a run (a pass after the first)
     uint8_t* heads2;
     uint64_t *lens2, *thr2, *ssa2, *esa2, *ds2, *de2;
     uint8_t* cont;
@@ -456,15 +458,15 @@ struct PieceWriter {
         if (esa2) esa2[o] = esa;
         if (ds2) ds2[o] = ds;
         if (de2) de2[o] = de;
-        cont[o] = first ? 0 : 1;
+        cont[o] = first ? cont0 : 1;
         first = false;
         ++o;
     }
 };
 
 __global__ void k_piece_fill(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr, const uint64_t* ssa,
-                             const uint64_t* esa, const uint64_t* ds, const uint64_t* de, const uint32_t* first_piece, uint64_t r,
-                             const uint64_t* S, const uint64_t* LFk, uint32_t span,
+                             const uint64_t* esa, const uint64_t* ds, const uint64_t* de, const uint8_t* cont_in,
+                             const uint32_t* first_piece, uint64_t r, const uint64_t* S, const uint64_t* LFk, uint32_t span,
                              uint8_t* heads2, uint64_t* lens2, uint64_t* thr2, uint64_t* ssa2, uint64_t* esa2, uint64_t* ds2,
                              uint64_t* de2, uint8_t* cont) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
@@ -472,13 +474,81 @@ __global__ void k_piece_fill(const uint8_t* heads, const uint64_t* lens, const u
     uint64_t lf, a, nb;
     image_of(S, LFk, r, k, lens[k], lf, a, nb);
     PieceWriter w{heads[k], thr[k], ssa2 ? ssa[k] : 0, esa2 ? esa[k] : 0, ds2 ? ds[k] : 0, de2 ? de[k] : 0,
-                  first_piece[k], true, heads2, lens2, thr2, ssa2, esa2, ds2, de2, cont};
+                  first_piece[k], true, (uint8_t)(cont_in ? cont_in[k] : 0), heads2, lens2, thr2, ssa2, esa2, ds2, de2, cont};
     for_each_piece(lens[k], lf, S, a, nb, span, w);
 }
 
 static int flatten_core(spx_index* ix, uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
                         const uint64_t* d_ssa, const uint64_t* d_esa, const uint64_t* d_ds, const uint64_t* d_de,
                         const uint8_t* d_cont);
+
+namespace {
+
+struct RunList {  // a run list on the device (the caller's arrays, or a generation of pieces)
+    uint64_t r = 0;
+    const uint8_t* heads = nullptr;
+    const uint64_t *lens = nullptr, *thr = nullptr, *ssa = nullptr, *esa = nullptr, *ds = nullptr, *de = nullptr;
+    const uint8_t* cont = nullptr;  // pieces after a run's first one (nullptr: none)
+};
+
+struct PieceGen {  // storage of one generation of pieces
+    DevBuf h, l, t, s, e, ds, de, c;
+    void release() {
+        for (DevBuf* b : {&h, &l, &t, &s, &e, &ds, &de, &c}) {
+            if (b->p) (void)hipFree(b->p);
+            b->p = nullptr;
+        }
+    }
+};
+
+// S (run starts, S[r] = n) and LF of every run start by run, for the images of a pass; ok = false: the run list is
+// not one flatten_core will accept (a run of length 0, a BWT too long) -- it says so itself
+int images_of_runs(const RunList& in, DevBuf& Sb, DevBuf& LFk, bool& ok, hipStream_t st) {
+    const uint64_t r = in.r;
+    ok = false;
+    DevBuf H, iota, Hs, Qall, ls, LFs, tmp, err;
+    SPX_HIP(H.alloc(r));
+    SPX_HIP(iota.alloc(r * 4));
+    SPX_HIP(Hs.alloc(r));
+    SPX_HIP(Qall.alloc(r * 4));
+    SPX_HIP(Sb.alloc((r + 1) * 8));
+    SPX_HIP(err.alloc(8));
+    SPX_HIP(hipMemsetAsync(err.p, 0, 8, st));
+    k_norm_heads<<<nblocks(r), TPB, 0, st>>>(in.heads, in.lens, r, H.as<uint8_t>(), iota.as<uint32_t>(), err.as<unsigned long long>());
+    size_t tb = 0, tb2 = 0;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in.lens, Sb.as<uint64_t>(), r, st));
+    SPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
+                                               Qall.as<uint32_t>(), r, 0, 8, st));
+    if (tb2 > tb) tb = tb2;
+    SPX_HIP(tmp.alloc(tb + 256));
+    size_t tbs = tb;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, in.lens, Sb.as<uint64_t>(), r, st));
+    uint64_t last_s = 0, last_len = 0;
+    unsigned long long bad = 0;
+    SPX_HIP(hipMemcpyAsync(&last_s, Sb.as<uint64_t>() + (r - 1), 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&last_len, in.lens + (r - 1), 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&bad, err.p, 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
+    const uint64_t n = last_s + last_len;
+    if (bad || n > MASK40 - 2) return SPX_OK;
+    SPX_HIP(hipMemcpyAsync(Sb.as<uint64_t>() + r, &n, 8, hipMemcpyHostToDevice, st));
+    tbs = tb;
+    SPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbs, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
+                                               Qall.as<uint32_t>(), r, 0, 8, st));
+    SPX_HIP(ls.alloc(r * 8));
+    SPX_HIP(LFs.alloc((r + 1) * 8));
+    SPX_HIP(LFk.alloc(r * 8));
+    k_gather_u64<<<nblocks(r), TPB, 0, st>>>(in.lens, Qall.as<uint32_t>(), r, ls.as<uint64_t>());
+    tbs = tb;
+    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, ls.as<uint64_t>(), LFs.as<uint64_t>(), r, st));
+    k_scatter_u64<<<nblocks(r), TPB, 0, st>>>(LFs.as<uint64_t>(), Qall.as<uint32_t>(), r, LFk.as<uint64_t>());
+    SPX_HIP(hipGetLastError());
+    SPX_HIP(hipStreamSynchronize(st));
+    ok = true;
+    return SPX_OK;
+}
+
+}  // namespace
 
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
@@ -498,122 +568,116 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(hipMemcpyAsync(&max_len, ml.p, 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipStreamSynchronize(st));
     }
-    uint32_t span = 16;
+    uint32_t span = 8;
     uint64_t min_run = 2048;
+    int passes = 4;
     if (const char* e = getenv("SPX_BALANCE_SPAN")) span = (uint32_t)atoi(e);
     if (const char* e = getenv("SPX_BALANCE_MIN_RUN")) min_run = (uint64_t)atoll(e);
-    bool balance = span > 0 && max_len >= min_run && max_len <= MASK40;
-    if (getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES") || (max_len <= PIECE_MAX && !balance))
-        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
+    if (const char* e = getenv("SPX_BALANCE_PASSES")) passes = atoi(e) < 1 ? 1 : atoi(e);
+    const bool want_balance = span > 0 && max_len >= min_run && max_len <= MASK40;
+    RunList orig;
+    orig.r = r;
+    orig.heads = d_heads;
+    orig.lens = d_lens;
+    orig.thr = d_thr;
+    orig.ssa = d_ssa;
+    orig.esa = d_esa;
+    orig.ds = d_ds;
+    orig.de = d_de;
+    auto as_it_is = [&] { return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr); };
+    if (getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES") || (max_len <= PIECE_MAX && !want_balance)) return as_it_is();
     const bool timing = getenv("SPX_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_bal = now();
-    // the images: S (run starts) and LF of every run start, by run (the arrays flatten_core builds again for the
-    // pieces: this pass is only made for an index with a long run)
-    DevBuf Sb, LFk;
-    if (balance) {
-        DevBuf H, iota, Hs, Qall, ls, LFs, tmp, err;
-        SPX_HIP(H.alloc(r));
-        SPX_HIP(iota.alloc(r * 4));
-        SPX_HIP(Hs.alloc(r));
-        SPX_HIP(Qall.alloc(r * 4));
-        SPX_HIP(Sb.alloc((r + 1) * 8));
-        SPX_HIP(err.alloc(8));
-        SPX_HIP(hipMemsetAsync(err.p, 0, 8, st));
-        k_norm_heads<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, r, H.as<uint8_t>(), iota.as<uint32_t>(), err.as<unsigned long long>());
-        size_t tb = 0, tb2 = 0;
-        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_lens, Sb.as<uint64_t>(), r, st));
-        SPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
-                                                   Qall.as<uint32_t>(), r, 0, 8, st));
-        if (tb2 > tb) tb = tb2;
-        SPX_HIP(tmp.alloc(tb + 256));
-        size_t tbs = tb;
-        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, d_lens, Sb.as<uint64_t>(), r, st));
-        uint64_t last_s = 0, last_len = 0;
-        unsigned long long bad = 0;
-        SPX_HIP(hipMemcpyAsync(&last_s, Sb.as<uint64_t>() + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipMemcpyAsync(&last_len, d_lens + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipMemcpyAsync(&bad, err.p, 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipStreamSynchronize(st));
-        const uint64_t n = last_s + last_len;
-        if (bad || n > MASK40 - 2) {
-            balance = false;  // (a run of length 0 / a BWT too long: flatten_core says so)
-        } else {
-            SPX_HIP(hipMemcpyAsync(Sb.as<uint64_t>() + r, &n, 8, hipMemcpyHostToDevice, st));
-            tbs = tb;
-            SPX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbs, H.as<uint8_t>(), Hs.as<uint8_t>(), iota.as<uint32_t>(),
-                                                       Qall.as<uint32_t>(), r, 0, 8, st));
-            SPX_HIP(ls.alloc(r * 8));
-            SPX_HIP(LFs.alloc((r + 1) * 8));
-            SPX_HIP(LFk.alloc(r * 8));
-            k_gather_u64<<<nblocks(r), TPB, 0, st>>>(d_lens, Qall.as<uint32_t>(), r, ls.as<uint64_t>());
-            tbs = tb;
-            SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tbs, ls.as<uint64_t>(), LFs.as<uint64_t>(), r, st));
-            k_scatter_u64<<<nblocks(r), TPB, 0, st>>>(LFs.as<uint64_t>(), Qall.as<uint32_t>(), r, LFk.as<uint64_t>());
-            SPX_HIP(hipGetLastError());
-            SPX_HIP(hipStreamSynchronize(st));
+
+    // Passes over the run list: pieces for length (the first pass) and for their images (every pass: the pieces of
+    // one pass are run boundaries in the next, which may push an image past the bound again; until nothing is cut
+    // or SPX_BALANCE_PASSES passes were made).
+    PieceGen gen[2];
+    RunList cur = orig;
+    for (int pass = 0; pass < passes; ++pass) {
+        const double t_pass = now();
+        DevBuf Sb, LFk;
+        bool balance = want_balance;
+        if (balance) {
+            const int rc = images_of_runs(cur, Sb, LFk, balance, st);
+            if (rc != SPX_OK) return rc;
         }
+        if (pass == 0 && !balance && max_len <= PIECE_MAX) return as_it_is();
+        if (pass > 0 && !balance) break;
+        const uint64_t* d_S = balance ? Sb.as<uint64_t>() : nullptr;
+        const uint64_t* d_LFk = balance ? LFk.as<uint64_t>() : nullptr;
+        const uint64_t rc_ = cur.r;
+        // how many pieces, and may the run list be extended at all?
+        DevBuf pieces, first_piece, cnt, present, tmp;
+        SPX_HIP(pieces.alloc((rc_ + 1) * 4));
+        SPX_HIP(first_piece.alloc((rc_ + 1) * 4));
+        SPX_HIP(cnt.alloc(16));
+        SPX_HIP(present.alloc(8 * 4));
+        SPX_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
+        SPX_HIP(hipMemsetAsync(present.p, 0, 32, st));
+        SPX_HIP(hipMemsetAsync(pieces.as<uint32_t>() + rc_, 0, 4, st));
+        k_piece_count<<<nblocks(rc_), TPB, 0, st>>>(cur.lens, cur.thr, rc_, d_S, d_LFk, balance ? span : 0, pieces.as<uint32_t>(),
+                                                     cnt.as<unsigned long long>(), cnt.as<unsigned long long>() + 1);
+        k_letters_present<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, rc_, present.as<unsigned int>());
+        size_t tb = 0;
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(rc_ + 1), st));
+        SPX_HIP(tmp.alloc(tb + 256));
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(rc_ + 1), st));
+        unsigned long long zero_thr = 0, span_max = 0;
+        unsigned int pres[8];
+        uint32_t r2_32 = 0;
+        SPX_HIP(hipMemcpyAsync(&zero_thr, cnt.p, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&span_max, cnt.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(pres, present.p, 32, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&r2_32, first_piece.as<uint32_t>() + rc_, 4, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
+        unsigned nletters = 0;
+        for (unsigned v : pres) nletters += (unsigned)__builtin_popcount(v);
+        const uint64_t r2 = r2_32;
+        if (timing)
+            fprintf(stderr, "[spx] pieces, pass %d: %llu rows -> %llu%s; longest image %llu runs (0: none over %u), longest run %llu; %.3f s\n",
+                    pass, (unsigned long long)rc_, (unsigned long long)r2, balance ? " (balanced)" : "", span_max, span, max_len,
+                    now() - t_pass);
+        // a non-first run with a zero threshold (thr_bv skips stored values: inserted pieces would shift which one a
+        // later run reads) / too many pieces: the run list stays as it is (the first pass: as the caller gave it)
+        if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 < rc_) {
+            if (pass == 0) return as_it_is();
+            break;
+        }
+        if (r2 == rc_) break;  // nothing to cut (any more)
+        PieceGen& g = gen[pass & 1];
+        SPX_HIP(g.h.alloc(r2));
+        SPX_HIP(g.l.alloc(r2 * 8));
+        SPX_HIP(g.t.alloc(r2 * 8));
+        if (cur.ssa) SPX_HIP(g.s.alloc(r2 * 8));
+        if (cur.esa) SPX_HIP(g.e.alloc(r2 * 8));
+        if (cur.ds) SPX_HIP(g.ds.alloc(r2 * 8));
+        if (cur.de) SPX_HIP(g.de.alloc(r2 * 8));
+        SPX_HIP(g.c.alloc(r2));
+        k_piece_fill<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, cur.lens, cur.thr, cur.ssa, cur.esa, cur.ds, cur.de, cur.cont,
+                                                    first_piece.as<uint32_t>(), rc_, d_S, d_LFk, balance ? span : 0, g.h.as<uint8_t>(),
+                                                    g.l.as<uint64_t>(), g.t.as<uint64_t>(), cur.ssa ? g.s.as<uint64_t>() : nullptr,
+                                                    cur.esa ? g.e.as<uint64_t>() : nullptr, cur.ds ? g.ds.as<uint64_t>() : nullptr,
+                                                    cur.de ? g.de.as<uint64_t>() : nullptr, g.c.as<uint8_t>());
+        SPX_HIP(hipGetLastError());
+        SPX_HIP(hipStreamSynchronize(st));
+        RunList next;
+        next.r = r2;
+        next.heads = g.h.as<uint8_t>();
+        next.lens = g.l.as<uint64_t>();
+        next.thr = g.t.as<uint64_t>();
+        next.ssa = cur.ssa ? g.s.as<uint64_t>() : nullptr;
+        next.esa = cur.esa ? g.e.as<uint64_t>() : nullptr;
+        next.ds = cur.ds ? g.ds.as<uint64_t>() : nullptr;
+        next.de = cur.de ? g.de.as<uint64_t>() : nullptr;
+        next.cont = g.c.as<uint8_t>();
+        cur = next;
+        gen[(pass + 1) & 1].release();  // the generation this one was cut from
+        if (!balance) break;            // (pieces for length only: nothing a further pass would change)
+        // (Sb, LFk, pieces, ... go out of scope here: the table flatten_core builds sizes itself against free memory)
     }
-    if (!balance && max_len <= PIECE_MAX)
-        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
-    const uint64_t* d_S = balance ? Sb.as<uint64_t>() : nullptr;
-    const uint64_t* d_LFk = balance ? LFk.as<uint64_t>() : nullptr;
-    if (!balance) span = 0;
-    // how many pieces, and may the run list be extended at all?
-    DevBuf pieces, first_piece, cnt, present, tmp;
-    SPX_HIP(pieces.alloc((r + 1) * 4));
-    SPX_HIP(first_piece.alloc((r + 1) * 4));
-    SPX_HIP(cnt.alloc(16));
-    SPX_HIP(present.alloc(8 * 4));
-    SPX_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
-    SPX_HIP(hipMemsetAsync(present.p, 0, 32, st));
-    SPX_HIP(hipMemsetAsync(pieces.as<uint32_t>() + r, 0, 4, st));
-    k_piece_count<<<nblocks(r), TPB, 0, st>>>(d_lens, d_thr, r, d_S, d_LFk, span, pieces.as<uint32_t>(), cnt.as<unsigned long long>(),
-                                               cnt.as<unsigned long long>() + 1);
-    k_letters_present<<<nblocks(r), TPB, 0, st>>>(d_heads, r, present.as<unsigned int>());
-    size_t tb = 0;
-    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
-    SPX_HIP(tmp.alloc(tb + 256));
-    SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(r + 1), st));
-    unsigned long long zero_thr = 0, span_max = 0;
-    unsigned int pres[8];
-    uint32_t r2_32 = 0;
-    SPX_HIP(hipMemcpyAsync(&zero_thr, cnt.p, 8, hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipMemcpyAsync(&span_max, cnt.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipMemcpyAsync(pres, present.p, 32, hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipMemcpyAsync(&r2_32, first_piece.as<uint32_t>() + r, 4, hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipStreamSynchronize(st));
-    unsigned nletters = 0;
-    for (unsigned v : pres) nletters += (unsigned)__builtin_popcount(v);
-    const uint64_t r2 = r2_32;
-    if (timing)
-        fprintf(stderr, "[spx] pieces: %llu runs -> %llu rows%s; longest image %llu runs (0: none over %u), longest run %llu; %.3f s\n",
-                (unsigned long long)r, (unsigned long long)r2, balance ? " (balanced)" : "", span_max, span, max_len, now() - t_bal);
-    if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 <= r)  // a non-first run with a zero threshold / too many pieces / none
-        return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr);
-    DevBuf h2, l2, t2, s2, e2, ds2, de2, cont;
-    SPX_HIP(h2.alloc(r2));
-    SPX_HIP(l2.alloc(r2 * 8));
-    SPX_HIP(t2.alloc(r2 * 8));
-    if (d_ssa) SPX_HIP(s2.alloc(r2 * 8));
-    if (d_esa) SPX_HIP(e2.alloc(r2 * 8));
-    if (d_ds) SPX_HIP(ds2.alloc(r2 * 8));
-    if (d_de) SPX_HIP(de2.alloc(r2 * 8));
-    SPX_HIP(cont.alloc(r2));
-    k_piece_fill<<<nblocks(r), TPB, 0, st>>>(d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, first_piece.as<uint32_t>(), r,
-                                              d_S, d_LFk, span, h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
-                                              d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr,
-                                              d_de ? de2.as<uint64_t>() : nullptr, cont.as<uint8_t>());
-    SPX_HIP(hipGetLastError());
-    SPX_HIP(hipStreamSynchronize(st));
-    // (the table below sizes itself against the memory that is free: nothing of this function's own stays allocated)
-    for (DevBuf* b : {&Sb, &LFk, &pieces, &first_piece, &tmp, &cnt, &present}) {
-        if (b->p) (void)hipFree(b->p);
-        b->p = nullptr;
-    }
-    return flatten_core(ix, r2, h2.as<uint8_t>(), l2.as<uint64_t>(), t2.as<uint64_t>(), d_ssa ? s2.as<uint64_t>() : nullptr,
-                        d_esa ? e2.as<uint64_t>() : nullptr, d_ds ? ds2.as<uint64_t>() : nullptr, d_de ? de2.as<uint64_t>() : nullptr,
-                        cont.as<uint8_t>());
+    if (cur.cont == nullptr) return as_it_is();
+    return flatten_core(ix, cur.r, cur.heads, cur.lens, cur.thr, cur.ssa, cur.esa, cur.ds, cur.de, cur.cont);
 }
 
 static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,

@@ -282,8 +282,8 @@ SPX_HD const Row& row_at(const DevIndex& ix, uint64_t k) {
 // at a time.  That is 0.02 gathers per character on the bench index and unbounded in principle (the move structure's
 // known worst case: a long run whose image covers thousands of short ones; tools/ff_model.py: 141 gathers per step on
 // Pareto-distributed run lengths).  So a piece also ends where its image has covered `span` runs (balancing in the
-// sense of Nishimoto & Tabei, one pass): at most span - 4 rows are walked on from any landing, for at most r / span * 2
-// more rows.
+// sense of Nishimoto & Tabei; spx_flatten.hip repeats the pass on its own output): at most span - 4 rows are walked on
+// from a landing.
 constexpr uint64_t PIECE_MAX = 65535;
 
 // run of position p: the largest k in [0, r) with S[k] <= p  (S[0] = 0, ascending, S[r] = n)

@@ -359,9 +359,9 @@ def test_long_runs_and_far_thresholds(gpu, oracle_mod):
 def test_balanced_pieces_bound_the_walk_past_the_landing_row(gpu, oracle_mod, monkeypatch):
     """Heavy-tailed run lengths (Pareto, longest run 7871 among runs of 1-2): the LF image of a long run covers up to
     1393 runs, and a step out of it walks on row by row from the fifth (42 gathers per step for positions drawn
-    uniformly, tools/ff_model.py).  The flatten step cuts such runs into pieces whose images cover at most 16 runs
-    (spx_layout.h: for_each_piece): 2 % more rows, the same answers in every mode, and a fraction of the row gathers;
-    SPX_BALANCE_SPAN=0 is the layout without it."""
+    uniformly, tools/ff_model.py).  The flatten step cuts such runs into pieces whose images cover at most 8 runs
+    (spx_layout.h: for_each_piece; the pass is repeated on its own output): some 6 % more rows, the same answers in
+    every mode, and a fraction of the row gathers; SPX_BALANCE_SPAN=0 is the layout without it."""
     rng = np.random.default_rng(8)
     r = 1 << 16
     idx = np.cumsum(rng.integers(1, 4, size=r)) % 4

@@ -20,8 +20,12 @@ total = int(seqs.numel())
 d_seqs = capi.pad_seqs(seqs)
 print(f"Pareto(1.2) run lengths, sigma 4: r {r}, n {int(lens.sum())}, longest run {int(lens.max())}; {nreads} reads x {m}, half simulated-positive", flush=True)
 ref = None
-for span in os.environ.get("BAL_SPANS", "0,64,16,8").split(","):
+for combo in os.environ.get("BAL_SPANS", "0,64,16,8").split(","):  # span or span:passes
+    span, _, passes = combo.partition(":")
     os.environ["SPX_BALANCE_SPAN"] = span
+    if passes:
+        os.environ["SPX_BALANCE_PASSES"] = passes
+        span = combo
     t0 = time.time()
     ix = capi.Index.from_raw(raw, 0)
     torch.cuda.synchronize()
@@ -42,6 +46,6 @@ for span in os.environ.get("BAL_SPANS", "0,64,16,8").split(","):
     if ref is None:
         ref = d_len[:total].clone()
     best = float(np.median(ms[1:]))
-    print(f"span {span:>2}: rows {d['flat_runs']} (+{100.0 * (d['flat_runs'] - r) / r:.2f} %), flatten {t_flat:.2f} s, walk {best:.3f} ms = "
+    print(f"span {span:>4}: rows {d['flat_runs']} (+{100.0 * (d['flat_runs'] - r) / r:.2f} %), flatten {t_flat:.2f} s, walk {best:.3f} ms = "
           f"{st['steps'] / best / 1e6:.2f} G steps/s, row gathers/step {st['row_loads'] / st['steps']:.3f}, dir/step {st['dir_loads'] / st['steps']:.3f}{same}", flush=True)
     ix.close()
