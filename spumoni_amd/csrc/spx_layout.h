@@ -311,8 +311,10 @@ SPX_HD uint32_t for_each_piece(uint64_t len, uint64_t lf, const uint64_t* S, uin
         uint64_t next = len - pos > PIECE_MAX ? pos + PIECE_MAX : len;
         if (balance && i + span - 1 <= nb) {
             // [pos, cand) covers the runs a + i - 1 .. a + i + span - 2: `span` of them
+            // (cand > pos on a run list whose lengths add up without overflow; the test keeps the loop finite on one
+            // that does not -- flatten_core refuses it afterwards)
             const uint64_t cand = S[a + i + span - 1] - lf;
-            if (cand < next) next = cand;
+            if (cand > pos && cand < next) next = cand;
         }
         f(pos, next - pos);
         ++np;
