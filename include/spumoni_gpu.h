@@ -98,7 +98,10 @@ spx_index *spx_index_from_runs(const uint8_t *heads, const uint64_t *lens, const
  * when mode == SPX_MODE_MS).  5-byte little-endian records (common.hpp:59-60). */
 spx_index *spx_index_load_raw(const char *prefix, int mode, int device);
 void spx_index_free(spx_index *ix);
-/* get_bwt_stats() (compute_ms_pml.cpp:171-173, 739-741): n = bwt size, r = runs */
+/* get_bwt_stats() (compute_ms_pml.cpp:171-173, 739-741): n = bwt size, r = runs -- the runs of the
+ * BWT as the files hold them.  (The flat layout may keep a run as several rows: one of 2^16 positions
+ * or more, or one whose LF image covers many runs, is laid out as consecutive pieces of the same head;
+ * spx_index_describe reports those rows as "flat_runs".  No result depends on it.)                    */
 int spx_index_stats(const spx_index *ix, uint64_t *n, uint64_t *r);
 /* bytes of HBM the flat layout occupies                                       */
 int spx_index_device_bytes(const spx_index *ix, uint64_t *bytes);
