@@ -8,7 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_piece_cuts_tile_the_run_and_bound_the_image(tmp_path):
     exe = str(tmp_path / "piece_cuts_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "piece_cuts_check.cpp")], check=True)
+    # (address + undefined-behaviour sanitizers: a read past the run starts S[0..r] would stop the program)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                    os.path.join(ROOT, "tests", "piece_cuts_check.cpp")], check=True)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "piece cuts ok" in p.stdout
@@ -33,7 +35,8 @@ def test_balancing_passes_on_the_host_match_what_the_device_printed(tmp_path):
         f.write(heads.tobytes())
         f.write(lens.astype(np.uint64).tobytes())
     exe = str(tmp_path / "balance_passes_host")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "balance_passes_host.cpp")], check=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                    os.path.join(ROOT, "tests", "balance_passes_host.cpp")], check=True)
     p = subprocess.run([exe, path, "8", "4"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     got = [tuple(int(x) for x in __import__("re").findall(r"\d+", line)[1:]) for line in p.stdout.splitlines()]
