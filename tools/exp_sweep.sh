@@ -6,7 +6,7 @@
 # 2048 (shipped) and at 64, interleaved on ONE box; flatten time, rows, reads/s, row gathers per character.
 #   usage (through gpurun):  bash tools/exp_sweep.sh > gpurun_out/gate_sweep.txt 2>&1
 # If neither moves by more than the box noise: ship the gate at 64 and take profiles/traffic.json again
-# (tools/profile_round.sh); better still, decide from the images themselves.
+# (tools/profile_round.sh); better still, decide from the images themselves ("Next").
 for rep in 1 2; do
   for gate in 2048 64; do
     SPX_BALANCE_MIN_RUN=$gate SPX_TIMING=1 timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --legs dna_m200,positive_100 2>/tmp/gate.err | tail -1 | \
