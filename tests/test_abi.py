@@ -53,3 +53,17 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".inc", ".cpp", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt, os.path.join(dp, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/spumoni_gpu.h compiles as C99 (-pedantic) on its own -- no C++, no torch or
+    HIP types in a signature."""
+    import subprocess
+
+    src = tmp_path / "h.c"
+    src.write_text('#include "spumoni_gpu.h"\nint main(void) { return SPX_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    code = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "spumoni_gpu.h")).read(), flags=re.S)  # (comments cite them)
+    assert "torch" not in code and "hipStream_t" not in code and "std::" not in code and "#include <hip" not in code
