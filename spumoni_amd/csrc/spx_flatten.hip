@@ -620,9 +620,9 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                                                      cnt.as<unsigned long long>(), cnt.as<unsigned long long>() + 1);
         k_letters_present<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, rc_, present.as<unsigned int>());
         size_t tb = 0;
-        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(rc_ + 1), st));
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), rc_ + 1, st));
         SPX_HIP(tmp.alloc(tb + 256));
-        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), (int)(rc_ + 1), st));
+        SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), rc_ + 1, st));
         unsigned long long zero_thr = 0, span_max = 0;
         unsigned int pres[8];
         uint32_t r2_32 = 0;
