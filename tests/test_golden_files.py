@@ -50,3 +50,22 @@ def test_fastq_tail_batch_is_dropped_like_the_reference_drops_it():
     assert records(os.path.join(fq, "expected_M", "reads.fa.lengths"), b">") == n_out
     fa = os.path.join(FILES, "dna_multiline_fasta")
     assert records(os.path.join(fa, "reads.fa"), b">read_") == records(os.path.join(fa, "expected_P", "reads.fa.pseudo_lengths"), b">")
+
+
+def test_committed_files_under_asan_ubsan(tmp_path):
+    """The same inputs through the ASan + UBSan build of the harness (multi-line FASTA, FASTQ with a dropped tail,
+    bytes >= 128 in the reads): no report, the same bytes."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all", "san"], stdout=subprocess.DEVNULL)
+    orc_asan = os.path.join(ROOT, "oracle", "orc_run_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for case in CASES:
+        work = tmp_path / case
+        shutil.copytree(os.path.join(FILES, case), work)
+        prefix, reads = str(work / "ref.fa"), str(work / "reads.fa")
+        for mode, doc, rep, bw in RUNS:
+            o = subprocess.run([orc_asan, prefix, reads, mode, str(doc), str(rep), str(bw), "n", prefix + ".rawtext"], capture_output=True, env=env)
+            assert o.returncode == 0, o.stderr.decode()[-2000:]
+            for bad in (b"AddressSanitizer", b"runtime error:", b"LeakSanitizer"):
+                assert bad not in o.stderr, o.stderr.decode()[-3000:]
+            for name in os.listdir(work / ("expected_" + mode)):
+                assert filecmp.cmp(str(work / name), str(work / ("expected_" + mode) / name), shallow=False), (case, mode, name)
