@@ -264,6 +264,9 @@ static int run_main(int argc, char** argv) {
     }
     if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
     if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && std::atoi(t) != 0;
+    // characters of reads per super-batch (64 MB; tests: a few thousand, so that a small input runs as many super-batches
+    // through the queue, the workers and the ordered writer)
+    if (const char* t = std::getenv("SPUMONI_SUPER_BATCH")) o.super_batch_chars = std::max<size_t>(1000, std::strtoull(t, nullptr, 10));
     // -t: the reference's helper threads walk the index; here the GPU does, and the threads
     // format the output text instead (default: up to 16 of the available cores)
     o.format_threads = o.threads > 1 ? o.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));

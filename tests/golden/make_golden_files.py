@@ -35,8 +35,8 @@ CASES = {
     "dna_fastq": (202, 1000, list(b"ACGT"), [ord("N"), ord("Z")], True, 40, 120),
     "promoted_alphabet_fasta": (203, 1500, [3, 4, 5, 60, 127, 128, 129, 200, 255], [250], False, 24, 70),
 }
-# (mode letter, doc, report, bin width): what is run for every case
-RUNS = [("P", 1, 1, 20), ("M", 1, 1, 25)]
+# (mode letter, doc, report, bin width): what is run for every case (the CLI refuses a bin width outside [50, 400])
+RUNS = [("P", 1, 1, 50), ("M", 1, 1, 60)]
 
 
 def write_reads(path, seqs, offs, rng, fastq, printable):

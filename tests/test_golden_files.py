@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = os.path.join(ROOT, "tests", "golden", "files")
 ORC_RUN = os.path.join(ROOT, "oracle", "orc_run")
 CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(FILES, "*")) if os.path.isdir(p))
-RUNS = [("P", 1, 1, 20), ("M", 1, 1, 25)]  # as in make_golden_files.py
+RUNS = [("P", 1, 1, 50), ("M", 1, 1, 60)]  # as in make_golden_files.py
 
 
 def test_fixtures_exist():

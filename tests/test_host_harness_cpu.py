@@ -1,0 +1,156 @@
+"""CPU tier: the C++ host above the C-ABI -- `spumoni run`'s harness (spumoni_amd/csrc/host: parser, one queue, a worker
+thread per device, the ordered writer, the report thread), the pml_t / ms_t mirror -- on a machine without a GPU.
+
+The host binary is the ordinary one; its libspumoni_gpu.so is, for these tests only, tests/fake_device: the same C-ABI
+answered by the CPU oracle (test infrastructure: built into a temporary directory, found through LD_LIBRARY_PATH; the
+product library still fails loudly without a device, tests/test_abi.py).  What is under test is the HOST code: batch
+segmentation, FASTA / FASTQ parsing, super-batches through the queue and several workers, headers spliced into the text
+the boundary returns, ordered writes, reports, fatal errors in read order, digestion options -- every output file
+byte-identical to the oracle harness (oracle/orc_run), also with many small super-batches on three workers, and under
+AddressSanitizer and ThreadSanitizer.  The HIP path itself is held against the oracle on the GPU (tests/test_gpu_*.py),
+where the same CLI tests run against the real library.
+"""
+import filecmp
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "spumoni_amd", "bin")
+FILES = os.path.join(ROOT, "tests", "golden", "files")
+
+
+@pytest.fixture(scope="module")
+def fake_device(tmp_path_factory, built_all):
+    """tests/fake_device/fake_spumoni_gpu.c + the oracle sources (no OpenMP: one thread per call, like one device
+    queue) as libspumoni_gpu.so in a temporary directory; the host binaries (plain, ASan, TSan) built."""
+    d = tmp_path_factory.mktemp("fake_device")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsigned-char", "-fPIC", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-shared",
+                           "-pthread", "-o", str(d / "libspumoni_gpu.so"), os.path.join(ROOT, "tests", "fake_device", "fake_spumoni_gpu.c"),
+                           os.path.join(ROOT, "oracle", "spumoni_oracle.c"), os.path.join(ROOT, "oracle", "orc_digest.c")])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "spumoni_amd", "csrc", "host"), "all", "san", "-j2"], stdout=subprocess.DEVNULL)
+    return str(d)
+
+
+@pytest.fixture
+def on_fake_device(fake_device, monkeypatch):
+    monkeypatch.setenv("LD_LIBRARY_PATH", fake_device + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    monkeypatch.setenv("SPUMONI_CACHE", "off")
+    monkeypatch.delenv("SPUMONI_GPUS", raising=False)
+    return fake_device
+
+
+def test_fake_device_exports_the_whole_boundary(fake_device):
+    from spumoni_amd import capi
+
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(fake_device, "libspumoni_gpu.so")], capture_output=True, text=True).stdout
+    have = {ln.split()[-1] for ln in out.splitlines() if " T spx_" in ln}
+    assert have == set(capi.EXPORTS)
+
+
+# ---- the CLI tests of tests/test_gpu_cli.py, host side, against the fake device --------------------------------------------
+def _cli():
+    from tests import test_gpu_cli
+
+    return test_gpu_cli
+
+
+def test_cli_pml_and_ms_with_reports_and_documents(on_fake_device, tmp_path):
+    T = _cli()
+    T.test_cli_pml_report_doc(None, tmp_path)
+    T.test_cli_ms_report_doc(None, tmp_path)
+
+
+def test_cli_fastq_validation_and_serialised_index(on_fake_device, tmp_path):
+    T = _cli()
+    (tmp_path / "fq").mkdir()
+    (tmp_path / "ser").mkdir()
+    T.test_cli_fastq_content_in_fa_named_file(None, tmp_path / "fq")
+    T.test_cli_validation_messages(None, tmp_path)
+    T.test_cli_reads_the_serialised_index(None, tmp_path / "ser")
+
+
+def test_cli_fatal_errors_come_in_read_order(on_fake_device, tmp_path, oracle_mod):
+    T = _cli()
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    T.test_cli_empty_read_is_fatal_after_earlier_reads_were_written(None, tmp_path / "a")
+    T.test_cli_read_empty_after_digestion_is_fatal_in_order(None, tmp_path / "b", oracle_mod)
+
+
+@pytest.mark.parametrize("digest,kw", [("m", ()), ("a", (2, 2))])
+def test_cli_with_minimizer_digestion(on_fake_device, tmp_path, oracle_mod, digest, kw):
+    _cli().test_cli_with_minimizer_digestion(None, tmp_path, oracle_mod, digest, kw)
+
+
+def test_pml_t_ms_t_mirror(on_fake_device, tmp_path, oracle_mod):
+    _cli().test_pml_t_ms_t_mirror_per_read_calls(None, tmp_path, oracle_mod)
+
+
+@pytest.mark.parametrize("host_format", [False, True])
+def test_many_small_super_batches_on_three_workers(on_fake_device, tmp_path, monkeypatch, host_format):
+    """SPUMONI_SUPER_BATCH=3000 characters and SPUMONI_GPUS=0,0,0: some twenty super-batches dealt to three workers
+    (three index replicas), results re-sequenced by the ordered writer and the report thread one batch behind -- the
+    same bytes as the oracle harness, with the text from the boundary and (SPUMONI_HOST_FORMAT=1) formatted on the host."""
+    T = _cli()
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0,0")
+    if host_format:
+        monkeypatch.setenv("SPUMONI_HOST_FORMAT", "1")
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 47, list(b"ACGT"), nreads=400)
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    batches = [int(ln.split("(")[1].split()[0]) for ln in r.stderr.decode().splitlines() if "super-batches" in ln]
+    assert len(batches) == 3 and sum(batches) >= 10 and min(batches) >= 1, batches
+    T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "60"], "-M")
+    T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, [], "-P", fastq=True)
+
+
+@pytest.mark.parametrize("case", sorted(os.listdir(FILES)) if os.path.isdir(FILES) else [])
+def test_cli_reproduces_the_committed_files(on_fake_device, tmp_path, monkeypatch, case):
+    """tests/golden/files through the host binary: the harness's output files are the committed ones."""
+    work = tmp_path / case
+    shutil.copytree(os.path.join(FILES, case), work)
+    monkeypatch.setenv("SPUMONI_TEXT", str(work / "ref.fa.rawtext"))
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "1500")
+    for mode, bw in (("P", "50"), ("M", "60")):  # (as tests/golden/make_golden_files.py ran the oracle harness)
+        r = subprocess.run([os.path.join(BIN, "spumoni"), "run", "-r", str(work / "ref"), "-p", str(work / "reads.fa"), "-n", "-" + mode, "-c", "-d",
+                            "-w", bw], capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        for name in sorted(os.listdir(work / ("expected_" + mode))):
+            assert filecmp.cmp(str(work / name), str(work / ("expected_" + mode) / name), shallow=False), (case, mode, name)
+
+
+# ---- the harness under sanitizers, no GPU runtime in the process ------------------------------------------------------------
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_harness_under_sanitizers_on_the_fake_device(on_fake_device, tmp_path, which):
+    """Three workers, many small super-batches, PML and MS with documents and reports, under -fsanitize=address,undefined
+    and -fsanitize=thread: no report at all (no HIP / HSA runtime threads in the process here, so every report would be
+    the host's), files identical to the ordinary binary's."""
+    T = _cli()
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 94, list(b"ACGT"), nreads=300)
+    exe = os.path.join(BIN, "spumoni_" + which)
+    files = {}
+    for tag, binary in (("plain", os.path.join(BIN, "spumoni")), (which, exe)):
+        d = tmp_path / tag
+        d.mkdir()
+        T._write_fasta(d / "reads.fa", seqs, offs, np.random.default_rng(5))
+        env = dict(os.environ, SPUMONI_GPUS="0,0,0", SPUMONI_SUPER_BATCH="4000", SPUMONI_TEXT=prefix + ".rawtext")
+        env["TSAN_OPTIONS"] = "report_signal_unsafe=0:history_size=4:exitcode=66"
+        # (no leak check: the slots' page-locked buffers outlive classify_reads on purpose, classify.cpp: the process ends)
+        env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=0"
+        env["UBSAN_OPTIONS"] = "print_stacktrace=1"
+        for mode in ("-P", "-M"):
+            pre = ["setarch", "x86_64", "-R"] if (binary.endswith("_tsan") and shutil.which("setarch")) else []
+            r = subprocess.run(pre + [binary, "run", "-r", ref, "-p", str(d / "reads.fa"), "-n", mode, "-c", "-d"], capture_output=True, env=env)
+            if binary.endswith("_tsan") and b"unexpected memory mapping" in r.stderr:
+                pytest.skip("this TSan runtime cannot start on this kernel (unexpected memory mapping), with or without ASLR")
+            assert r.returncode == 0, r.stderr.decode(errors="replace")[-4000:]
+            for bad in (b"AddressSanitizer", b"runtime error:", b"ThreadSanitizer", b"LeakSanitizer"):
+                assert bad not in r.stderr, r.stderr.decode(errors="replace")[-6000:]
+        files[tag] = {n: open(d / n, "rb").read() for n in sorted(os.listdir(d)) if n != "reads.fa"}
+    assert files["plain"].keys() == files[which].keys() and len(files["plain"]) >= 5
+    assert files["plain"] == files[which]
