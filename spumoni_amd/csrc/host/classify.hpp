@@ -27,7 +27,7 @@ struct RunOptions {  // SpumoniRunOptions, include/spumoni_main.hpp:233-250
     std::string text_file;
     size_t super_batch_chars = 64u << 20;
     size_t format_threads = 1;  // host threads that turn results into text (-t, or the core count)
-    bool report_only = false;   // SPUMONI_REPORT_ONLY=1 with -c: only <pattern>.report gets content
+    bool report_only = false;   // SPUMONI_REPORT_ONLY=1 with -P -c: <pattern>.pseudo_lengths stays empty (PML only)
 };
 
 // One spx_index per device: flattened (or read from the flat-layout cache) once, then replicated

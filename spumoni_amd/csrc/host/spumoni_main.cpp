@@ -263,7 +263,9 @@ static int run_main(int argc, char** argv) {
         if (o.devices.empty()) o.devices.push_back(0);
     }
     if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
-    if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && std::atoi(t) != 0;
+    // (PML only: with -M the lengths are what the report is made from and every stream is written -- the host-formatting
+    // path used to leave <pattern>.lengths empty there while the device-text path wrote it)
+    if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && !o.ms && std::atoi(t) != 0;
     // characters of reads per super-batch (64 MB; tests: a few thousand, so that a small input runs as many super-batches
     // through the queue, the workers and the ordered writer)
     if (const char* t = std::getenv("SPUMONI_SUPER_BATCH")) o.super_batch_chars = std::max<size_t>(1000, std::strtoull(t, nullptr, 10));

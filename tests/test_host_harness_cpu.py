@@ -154,3 +154,38 @@ def test_harness_under_sanitizers_on_the_fake_device(on_fake_device, tmp_path, w
         files[tag] = {n: open(d / n, "rb").read() for n in sorted(os.listdir(d)) if n != "reads.fa"}
     assert files["plain"].keys() == files[which].keys() and len(files["plain"]) >= 5
     assert files["plain"] == files[which]
+
+
+def test_long_read_and_report_only_on_both_formatting_paths(on_fake_device, tmp_path):
+    """A read of 70 000 characters (no 16-bit values for its super-batch) between short ones, PML and MS with documents and
+    reports, text from the boundary and formatted on the host, under ASan: the oracle harness's bytes.  SPUMONI_REPORT_ONLY=1
+    empties <pattern>.pseudo_lengths only (PML; with -M the lengths are what the report is made from: no effect) -- on both
+    paths alike (the host-formatting path used to leave .lengths empty with -M)."""
+    T = _cli()
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 96, list(b"ACGT"), n=90000, nreads=30)
+    text = np.fromfile(prefix + ".rawtext", dtype=np.uint8)
+    reads = str(tmp_path / "reads.fa")
+    with open(reads, "wb") as f:
+        f.write(b">short_1\n" + text[100:400].tobytes() + b"\n")
+        f.write(b">long one\n" + text[2000:72000].tobytes() + b"\n")
+        f.write(b">short_2 x\n" + text[500:900].tobytes().lower() + b"\n")
+    exe = os.path.join(BIN, "spumoni_asan")
+    for mode, exts in (("P", (".pseudo_lengths", ".doc_numbers", ".report")), ("M", (".lengths", ".pointers", ".doc_numbers", ".report"))):
+        o = subprocess.run([T.ORC_RUN, prefix, reads, mode, "1", "1", "150", "n", prefix + ".rawtext"], capture_output=True)
+        assert o.returncode == 0, o.stderr.decode()
+        for e in exts:
+            shutil.move(reads + e, str(tmp_path / ("want" + e)))
+        for host_format in (False, True):
+            for report_only in (False, True):
+                env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0")
+                if host_format:
+                    env["SPUMONI_HOST_FORMAT"] = "1"
+                if report_only:
+                    env["SPUMONI_REPORT_ONLY"] = "1"
+                r = subprocess.run([exe, "run", "-r", ref, "-p", reads, "-n", "-" + mode, "-c", "-d"], capture_output=True, env=env)
+                assert r.returncode == 0 and b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr.decode(errors="replace")[-3000:]
+                for e in exts:
+                    if report_only and e == ".pseudo_lengths":
+                        assert os.path.getsize(reads + e) == 0
+                    else:
+                        assert filecmp.cmp(reads + e, str(tmp_path / ("want" + e)), shallow=False), (mode, host_format, report_only, e)
