@@ -189,3 +189,15 @@ def test_long_read_and_report_only_on_both_formatting_paths(on_fake_device, tmp_
                         assert os.path.getsize(reads + e) == 0
                     else:
                         assert filecmp.cmp(reads + e, str(tmp_path / ("want" + e)), shallow=False), (mode, host_format, report_only, e)
+
+
+@pytest.mark.timeout(900)
+def test_cli_differential_fuzz_against_the_oracle_harness(on_fake_device, tmp_path):
+    """tools/cli_fuzz_cpu.py, forty seeds: random FASTA / FASTQ files (headers without an id, empty and multi-line reads,
+    CR LF, blank lines, no final newline, ...) through the ASan build of `spumoni run` on the fake device and through the
+    oracle harness -- same exit status, same error message, same bytes in every file, also after a fatal error.
+    (1 400 further seeds: profiles/r03_cli_fuzz_cpu.txt)"""
+    env = dict(os.environ, FAKE_DEVICE_DIR=on_fake_device, CLI_FUZZ_DIR=str(tmp_path / "fuzz"))
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "cli_fuzz_cpu.py"), "40", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "bad 0" in r.stdout
