@@ -23,18 +23,6 @@ BIN = os.path.join(ROOT, "spumoni_amd", "bin")
 FILES = os.path.join(ROOT, "tests", "golden", "files")
 
 
-@pytest.fixture(scope="module")
-def fake_device(tmp_path_factory, built_all):
-    """tests/fake_device/fake_spumoni_gpu.c + the oracle sources (no OpenMP: one thread per call, like one device
-    queue) as libspumoni_gpu.so in a temporary directory; the host binaries (plain, ASan, TSan) built."""
-    d = tmp_path_factory.mktemp("fake_device")
-    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsigned-char", "-fPIC", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-shared",
-                           "-pthread", "-o", str(d / "libspumoni_gpu.so"), os.path.join(ROOT, "tests", "fake_device", "fake_spumoni_gpu.c"),
-                           os.path.join(ROOT, "oracle", "spumoni_oracle.c"), os.path.join(ROOT, "oracle", "orc_digest.c")])
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "spumoni_amd", "csrc", "host"), "all", "san", "-j2"], stdout=subprocess.DEVNULL)
-    return str(d)
-
-
 @pytest.fixture
 def on_fake_device(fake_device, monkeypatch):
     monkeypatch.setenv("LD_LIBRARY_PATH", fake_device + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
