@@ -1012,7 +1012,10 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
                 }
             }
             t_write.stop();
-            const bool last = s.last;
+            // a super-batch that ends in a deferred fatal (a read empty after digestion is only known once the batch is
+            // back from its device) is the last one written: the report thread, one batch behind, stops the run there,
+            // and nothing of a later super-batch may reach the files before it does (the reference stops AT the read)
+            const bool last = s.last || s.deferred != 0;
             report_q.push(i);
             if (last) break;
         }

@@ -11,10 +11,22 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <stdexcept>
 #include <thread>
 
 namespace spumoni_host {
+
+// The reference's FATAL_ERROR / FATAL_WARNING end in std::exit(1) on its one thread.  Here a fatal error is raised on
+// whichever thread meets it (the report thread, for a read that is empty after digestion) while the parser and the
+// device workers are still at work: std::exit would run the static destructors -- the page-locked pool, the library's
+// own -- under their feet (found as a heap-use-after-free by the CPU fuzz, tools/cli_fuzz_cpu.py).  So: flush what is
+// buffered (the output files are written with pwrite and need nothing) and leave without them.
+[[noreturn]] static void leave(int code) {
+    std::cout.flush();
+    std::fflush(nullptr);
+    std::_Exit(code);
+}
 
 void fatal_error(const char* fmt, ...) {  // FATAL_ERROR, include/spumoni_main.hpp:32-33
     std::fprintf(stderr, "\n\033[31mError: \033[0m");
@@ -23,7 +35,7 @@ void fatal_error(const char* fmt, ...) {  // FATAL_ERROR, include/spumoni_main.h
     std::vfprintf(stderr, fmt, ap);
     va_end(ap);
     std::fprintf(stderr, "\n\n");
-    std::exit(1);
+    leave(1);
 }
 
 void fatal_warning(const char* fmt, ...) {  // FATAL_WARNING, include/spumoni_main.hpp:28-29
@@ -33,7 +45,7 @@ void fatal_warning(const char* fmt, ...) {  // FATAL_WARNING, include/spumoni_ma
     std::vfprintf(stderr, fmt, ap);
     va_end(ap);
     std::fprintf(stderr, "\n\n");
-    std::exit(1);
+    leave(1);
 }
 
 ReadFile::ReadFile(const std::string& path, unsigned threads) {

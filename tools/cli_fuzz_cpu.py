@@ -71,8 +71,22 @@ for seed in range(first, first + N):
                SPUMONI_SUPER_BATCH=str(int(rng.choice([1000, 2500, 10**7]))), SPUMONI_GPUS=",".join(["0"] * int(rng.integers(1, 4))))
     if rng.random() < 0.3: env["SPUMONI_HOST_FORMAT"] = "1"
     flags = (["-c"] if rep else []) + (["-d"] if doc else [])
-    r = subprocess.run([HOST, "run", "-r", ref, "-p", str(tmp / "cli" / "reads.fa"), "-n", "-" + mode] + flags, capture_output=True, env=env)
-    o = subprocess.run([T.ORC_RUN, prefix, str(tmp / "orc" / "reads.fa"), mode, str(doc), str(rep), "150", "n", prefix + ".rawtext"], capture_output=True)
+    # digestion (run -m / -a, compute_ms_pml.cpp:919-931): which index the digested reads are searched in does not matter
+    # to the host; -m wants the index under <ref>.bin
+    digest = str(rng.choice(["n", "n", "m", "a"]))
+    kw, orc_kw, pfx, ref_run = [], [], prefix, ref
+    if digest != "n":
+        k = int(rng.integers(1, 5)); w = k + int(rng.integers(0, 9))
+        kw, orc_kw = ["-K", str(k), "-W", str(w)], ["--k", str(k), "--w", str(w)]
+        if digest == "m":  # (a directory of its own: <ref>.fa and <ref>.bin side by side are refused)
+            ref_run = str(tmp / "promoted" / "ref"); pfx = ref_run + ".bin"
+            if not os.path.exists(pfx):
+                (tmp / "promoted").mkdir(exist_ok=True)
+                for f in os.listdir(tmp):
+                    if f.startswith("ref.fa"):
+                        shutil.copy(tmp / f, tmp / "promoted" / ("ref.bin" + f[len("ref.fa"):]))
+    r = subprocess.run([HOST, "run", "-r", ref_run, "-p", str(tmp / "cli" / "reads.fa"), "-" + digest, "-" + mode] + flags + kw, capture_output=True, env=env)
+    o = subprocess.run([T.ORC_RUN, pfx, str(tmp / "orc" / "reads.fa"), mode, str(doc), str(rep), "150", digest, prefix + ".rawtext"] + orc_kw, capture_output=True)
     problems = []; fatals += o.returncode != 0; empties += (len(data) == 0)
     if b"Sanitizer" in r.stderr or b"runtime error" in r.stderr: problems.append("sanitizer")
     if (r.returncode == 0) != (o.returncode == 0): problems.append(f"rc {r.returncode} vs {o.returncode}")
@@ -88,7 +102,7 @@ for seed in range(first, first + N):
         elif ea and not filecmp.cmp(str(a), str(b), shallow=False): problems.append(f"{e} differs ({a.stat().st_size} vs {b.stat().st_size})")
     if problems:
         bad += 1
-        print("seed", seed, mode, flags, {k: env.get(k) for k in ("SPUMONI_SUPER_BATCH", "SPUMONI_GPUS", "SPUMONI_HOST_FORMAT")}, problems)
+        print("seed", seed, mode, digest, kw, flags, {k: env.get(k) for k in ("SPUMONI_SUPER_BATCH", "SPUMONI_GPUS", "SPUMONI_HOST_FORMAT")}, problems)
         shutil.copy(tmp / "cli" / "reads.fa", tmp / f"bad_{seed}.fa")
         if bad > 12: break
 print("seeds", first, "..", first + N - 1, "bad", bad, "runs that ended in a fatal error", fatals, "empty files", empties)
