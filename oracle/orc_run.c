@@ -8,7 +8,9 @@
  * HIP-backed `spumoni run` writes.  PARITY UNPINNED (see spumoni_oracle.h).
  *
  * usage: orc_run <ref_file incl. .fa/.bin> <reads file> <P|M> <doc 0|1> <report 0|1>
- *                <bin_width> <flags: n|m|a> [text file for MS] [--dump-reads]
+ *                <bin_width> <flags: n|m|a|g> [text file for MS] [--dump-reads]
+ *        g: general text (classify_general_reads_pml / _ms, :1219-1297): the reads file is raw bytes, every read
+ *           ends in \x01, reads are named read_<k>; no upper-casing, no documents, no report
  * Index input: <ref_file>.bwt.heads/.bwt.len/.thr_pos[/.ssa/.esa], <ref_file>.doc,
  * <ref_file>.pmlnulldb/.msnulldb.   Output: <reads>.pseudo_lengths etc.
  */
@@ -298,6 +300,43 @@ int main(int argc, char **argv) {
         report_file = fopen(path, "w");
         fprintf(report_file, "%-30s%-15s%-19s%-2zu%-5s%-12s%-12s\n", "read id:", "status:", "avg max-value (thr=",
                 max_value_thr, "):", "above thr:", "below thr:");
+    }
+
+    if (argv[7][0] == 'g') { /* :1219-1297 */
+        uint64_t *gl = NULL, *gp = NULL;
+        size_t gcap = 0, start = 0, nr = 0;
+        for (size_t i = 0; i < fsz; ++i) {
+            if (input.d[i] != '\x01') continue; /* (what follows the last separator is never a read, :1236-1256) */
+            const char *rd = input.d + start;
+            const size_t m = i - start;
+            if (m + 1 > gcap) {
+                gcap = 2 * (m + 1);
+                gl = (uint64_t *)realloc(gl, gcap * 8);
+                gp = (uint64_t *)realloc(gp, gcap * 8);
+            }
+            if (m) {
+                if (!is_ms) {
+                    orc_pml_query(ix, rd, m, gl);
+                } else {
+                    orc_ms_query(ix, rd, m, gp);
+                    orc_ms_lengths(rd, m, gp, text, n_text, gl);
+                }
+            }
+            fprintf(lengths_file, ">read_%zu\n", nr);
+            for (size_t j = 0; j < m; ++j) fprintf(lengths_file, "%llu ", (unsigned long long)gl[j]);
+            fputc('\n', lengths_file);
+            if (is_ms) {
+                fprintf(pointers_file, ">read_%zu\n", nr);
+                for (size_t j = 0; j < m; ++j) fprintf(pointers_file, "%llu ", (unsigned long long)gp[j]);
+                fputc('\n', pointers_file);
+            }
+            start = i + 1;
+            nr++;
+        }
+        fclose(lengths_file);
+        if (pointers_file) fclose(pointers_file);
+        fprintf(stderr, "orc_run: %zu reads\n", nr);
+        return 0;
     }
 
     str id = {0}, seq = {0}, seq_view = {0};

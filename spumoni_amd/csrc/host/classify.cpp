@@ -285,6 +285,7 @@ struct PinnedBuf {
         n = count;
     }
     void append(const T* src, size_t count) {
+        if (count == 0) return;  // (an empty read of a general-text file: nothing to copy, and p may still be null)
         reserve(n + count);
         std::memcpy(p + n, src, count * sizeof(T));
         n += count;
