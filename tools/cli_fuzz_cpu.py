@@ -15,7 +15,8 @@ from tests import test_gpu_cli as T
 tmp = pathlib.Path(os.environ.get('CLI_FUZZ_DIR', '/tmp/cli_fuzz')); shutil.rmtree(tmp, ignore_errors=True); tmp.mkdir(parents=True)
 ref, prefix, seqs, offs, rng0 = T._setup(tmp, 97, list(b"ACGT"), n=8000, nreads=10)
 text = np.fromfile(prefix + ".rawtext", dtype=np.uint8)
-HOST = os.path.join(ROOT, 'spumoni_amd', 'bin', 'spumoni_asan')
+HOST = os.path.join(ROOT, 'spumoni_amd', 'bin', os.environ.get('CLI_FUZZ_BIN', 'spumoni_asan'))  # spumoni_tsan: races instead of addresses
+PRE = ["setarch", "x86_64", "-R"] if HOST.endswith("_tsan") and shutil.which("setarch") else []  # (gcc 11's TSan wants ASLR off here)
 
 def rand_seq(rng, n):
     if rng.random() < 0.6:
@@ -67,7 +68,7 @@ for seed in range(first, first + N):
     for d in ("cli", "orc"):
         shutil.rmtree(tmp / d, ignore_errors=True); (tmp / d).mkdir()
         (tmp / d / "reads.fa").write_bytes(data)
-    env = dict(os.environ, LD_LIBRARY_PATH=os.environ.get('FAKE_DEVICE_DIR', '/tmp/fake'), SPUMONI_CACHE="off", SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0",
+    env = dict(os.environ, LD_LIBRARY_PATH=os.environ.get('FAKE_DEVICE_DIR', '/tmp/fake'), SPUMONI_CACHE="off", SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_signal_unsafe=0:history_size=4",
                SPUMONI_SUPER_BATCH=str(int(rng.choice([1000, 2500, 10**7]))), SPUMONI_GPUS=",".join(["0"] * int(rng.integers(1, 4))))
     if rng.random() < 0.3: env["SPUMONI_HOST_FORMAT"] = "1"
     flags = (["-c"] if rep else []) + (["-d"] if doc else [])
@@ -85,7 +86,7 @@ for seed in range(first, first + N):
                 for f in os.listdir(tmp):
                     if f.startswith("ref.fa"):
                         shutil.copy(tmp / f, tmp / "promoted" / ("ref.bin" + f[len("ref.fa"):]))
-    r = subprocess.run([HOST, "run", "-r", ref_run, "-p", str(tmp / "cli" / "reads.fa"), "-" + digest, "-" + mode] + flags + kw, capture_output=True, env=env)
+    r = subprocess.run(PRE + [HOST, "run", "-r", ref_run, "-p", str(tmp / "cli" / "reads.fa"), "-" + digest, "-" + mode] + flags + kw, capture_output=True, env=env)
     o = subprocess.run([T.ORC_RUN, pfx, str(tmp / "orc" / "reads.fa"), mode, str(doc), str(rep), "150", digest, prefix + ".rawtext"] + orc_kw, capture_output=True)
     problems = []; fatals += o.returncode != 0; empties += (len(data) == 0)
     if b"Sanitizer" in r.stderr or b"runtime error" in r.stderr: problems.append("sanitizer")
