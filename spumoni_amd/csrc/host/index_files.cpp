@@ -88,6 +88,8 @@ bool read_int_vector(Cursor& c, std::vector<uint64_t>& out) {
     uint8_t width = 0;
     if (!c.get(&bits, 8) || !c.get(&width, 1)) return false;
     const uint64_t words = (bits + 63) / 64;
+    // (a size field is believed only as far as the file reaches: a damaged one must not size an allocation)
+    if (bits > ~0ull - 63 || words > (c.b.size() - c.p) / 8) return false;
     std::vector<uint64_t> w(words);
     if (words && !c.get(w.data(), words * 8)) return false;
     if (width == 0 || width > 64) {
@@ -163,7 +165,7 @@ struct BitVec {
 };
 
 bool read_bit_vector(Cursor& c, BitVec& out) {
-    if (!c.get(&out.bits, 8)) return false;
+    if (!c.get(&out.bits, 8) || out.bits > ~0ull - 63) return false;
     const uint64_t words = (out.bits + 63) / 64;
     if (words > (c.b.size() - c.p) / 8) return false;
     out.w.resize(words);
@@ -209,6 +211,7 @@ bool read_sparse_sd(Cursor& c, std::vector<uint64_t>& ones, uint64_t& universe) 
     if (!read_int_vector(c, low) || !read_bit_vector(c, high)) return false;
     if (!skip_select_mcl(c) || !skip_select_mcl(c)) return false;
     if (size != u) return false;
+    if (n > high.bits) return false;  // (as many ones as the high part has bits, at most)
     ones.reserve(n);
     uint64_t i = 0;
     for (uint64_t p = 0; p < high.bits && i < n; ++p) {
@@ -248,6 +251,7 @@ bool read_wt_huff(Cursor& c, std::vector<uint8_t>& seq) {
     std::vector<int> leaf_symbol(nnodes, -1);
     for (int ch = 0; ch < 256; ++ch)
         if (c_to_leaf[ch] != 0xffff && c_to_leaf[ch] < nnodes) leaf_symbol[c_to_leaf[ch]] = ch;
+    if (size > bv.bits) return false;  // (the root level alone holds one bit per symbol)
     seq.assign(size, 0);
     if (size == 0) return true;
     // iterative expansion: every node owns a list of output positions

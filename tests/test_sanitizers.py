@@ -165,3 +165,14 @@ def test_run_harness_under_sanitizers(san_bins, tmp_path, which):
         files[tag] = {n: open(d / n, "rb").read() for n in sorted(os.listdir(d)) if n != "reads.fa"}
     assert files["plain"].keys() == files[which].keys() and len(files["plain"]) >= 5
     assert files["plain"] == files[which]
+
+
+def test_serialised_index_reader_survives_damaged_files(san_bins, tmp_path):
+    """tools/index_reader_fuzz.py, 160 mutations of a valid <ref>.thrbv.spumoni (truncations, flipped bytes, wild size
+    words) through the ASan + UBSan build: decoded or refused with a message, never a report, an abort or a hang.  (Its
+    first run found size fields that sized 2^60-byte allocations before they were held against the file's length.)"""
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "index_reader_fuzz.py"), "160"], capture_output=True, text=True,
+                       env=dict(os.environ, INDEX_FUZZ_DIR=str(tmp_path / "fuzz")), timeout=900)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
