@@ -422,3 +422,37 @@ def test_stale_cache_is_not_used(tmp_path):
     os.remove(prefix + ".pml.spx")
     err, fresh = run("off")
     assert third == fresh and third != first
+
+
+@pytest.mark.xfail(strict=False, reason="written when round 3's GPU minutes were spent: its host side is verified on the CPU "
+                                        "(tests/test_host_harness_cpu.py, against tests/fake_device) and it is expected to pass on the "
+                                        "device; marked so that a surprise on its first GPU run cannot stop the suite")
+def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch):
+    """SPUMONI_SUPER_BATCH=3000 characters and SPUMONI_GPUS=0,0: some twenty super-batches through two workers (two index
+    replicas on one device), the ordered writer and the report thread, text from the device and formatted on the host:
+    the oracle harness's bytes.  And a read that is empty after digestion in the FIRST of many super-batches: nothing of a
+    later super-batch may reach the files (the defect the CPU fuzz found in round 3)."""
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0")
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 48, list(b"ACGT"), nreads=400)
+    r = _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    batches = [int(ln.split("(")[1].split()[0]) for ln in r.stderr.decode().splitlines() if "super-batches" in ln]
+    assert len(batches) == 2 and sum(batches) >= 10, batches
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "60"], "-M")
+    monkeypatch.setenv("SPUMONI_HOST_FORMAT", "1")
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    monkeypatch.delenv("SPUMONI_HOST_FORMAT")
+    # fatal in the first super-batch, -a (DNA minimizers): r0 is shorter than one window
+    for d in ("gpu", "orc"):
+        with open(tmp_path / d / "fatal.fa", "w") as f:
+            f.write(">r0\nCTA\n")
+            for q in range(1, 200):
+                s = seqs[offs[q]: offs[q + 1]].tobytes().decode()
+                if len(s) > 40:
+                    f.write(f">r{q}\n{s}\n")
+    r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(tmp_path / "gpu" / "fatal.fa"), "-a", "-P", "-c", "-K", "3", "-W", "11"], capture_output=True)
+    o = subprocess.run([ORC_RUN, prefix, str(tmp_path / "orc" / "fatal.fa"), "P", "0", "1", "150", "a", "--k", "3", "--w", "11"], capture_output=True)
+    assert r.returncode == 1 and o.returncode == 1 and b"r0 was empty after digestion" in r.stderr
+    for e in (".pseudo_lengths", ".report"):
+        assert filecmp.cmp(str(tmp_path / "gpu" / "fatal.fa") + e, str(tmp_path / "orc" / "fatal.fa") + e, shallow=False), e
+    assert os.path.getsize(str(tmp_path / "gpu" / "fatal.fa") + ".pseudo_lengths") == 0

@@ -220,3 +220,10 @@ def test_general_text_mode(on_fake_device, tmp_path):
                        (["-n", "-t", "2"], b"multi-threading is not available")):
         r = subprocess.run([os.path.join(BIN, "spumoni"), "run", "-r", ref, "-p", str(tmp_path / "cli" / "pattern.txt"), "-g", "-P"] + extra, capture_output=True)
         assert r.returncode == 1 and msg in r.stderr, r.stderr.decode()[-500:]
+
+
+def test_the_gpu_tiers_new_multi_batch_test_host_side(on_fake_device, tmp_path, monkeypatch):
+    """tests/test_gpu_cli.py::test_cli_many_small_super_batches_on_the_device (not yet run on a GPU: xfail-marked there)
+    passes host side."""
+    fn = _cli().test_cli_many_small_super_batches_on_the_device
+    getattr(fn, "__wrapped__", fn)(None, tmp_path, monkeypatch)
