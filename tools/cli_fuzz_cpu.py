@@ -72,6 +72,7 @@ for seed in range(first, first + N):
                SPUMONI_SUPER_BATCH=str(int(rng.choice([1000, 2500, 10**7]))), SPUMONI_GPUS=",".join(["0"] * int(rng.integers(1, 4))))
     if rng.random() < 0.3: env["SPUMONI_HOST_FORMAT"] = "1"
     flags = (["-c"] if rep else []) + (["-d"] if doc else [])
+    if rng.random() < 0.5: flags += ["-t", str(int(rng.integers(1, 9)))]  # (-t: the host threads that parse and format)
     # digestion (run -m / -a, compute_ms_pml.cpp:919-931): which index the digested reads are searched in does not matter
     # to the host; -m wants the index under <ref>.bin
     digest = str(rng.choice(["n", "n", "m", "a"]))
