@@ -337,7 +337,8 @@ def main(argv=None):
             f.write(b">read_%d\n" % i + rd.tobytes() + b"\n")
     stats = {"ms": [0], "pml": [0]}
     ks_thr = {"ms": 0.0, "pml": 0.0}
-    if null_reads and torch.cuda.is_available():
+    # (the statistics come from the library's path: asked of the library itself whether it has a device to run it on)
+    if null_reads and capi.lib().spx_device_count() > 0:
         rev = [np.frombuffer(rd.tobytes().upper(), dtype=np.uint8)[::-1] for rd in null_reads]
         seqs = np.ascontiguousarray(np.concatenate(rev))
         offs = np.concatenate([[0], np.cumsum([r.size for r in rev])]).astype(np.uint64)

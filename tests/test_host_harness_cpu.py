@@ -227,3 +227,19 @@ def test_the_gpu_tiers_new_multi_batch_test_host_side(on_fake_device, tmp_path, 
     passes host side."""
     fn = _cli().test_cli_many_small_super_batches_on_the_device
     getattr(fn, "__wrapped__", fn)(None, tmp_path, monkeypatch)
+
+
+def test_builder_files_run_end_to_end(on_fake_device, tmp_path, monkeypatch):
+    """FASTA files -> spumoni_amd.build_index (suffix sorting with torch on the CPU here; the null reads' statistics through
+    the binding, i.e. the fake device) -> `spumoni run` -> the oracle harness's files; the null reads are the reference's
+    draws and both null databases re-derive from the oracle harness's output
+    (tests/test_gpu_cli.py::test_end_to_end_from_fasta_with_our_builder, host side)."""
+    monkeypatch.setenv("SPUMONI_GPU_LIB", os.path.join(on_fake_device, "libspumoni_gpu.so"))
+    _cli().test_end_to_end_from_fasta_with_our_builder(None, tmp_path)
+
+
+def test_minimizer_builder_files_run_end_to_end(on_fake_device, tmp_path, monkeypatch):
+    """FASTA -> build_index -m (digestion through the binding) -> run -m: positives FOUND, nulls not
+    (tests/test_gpu_cli.py::test_end_to_end_minimizer_index_from_fasta, host side)."""
+    monkeypatch.setenv("SPUMONI_GPU_LIB", os.path.join(on_fake_device, "libspumoni_gpu.so"))
+    _cli().test_end_to_end_minimizer_index_from_fasta(None, tmp_path)
