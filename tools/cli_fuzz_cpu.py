@@ -71,7 +71,15 @@ for seed in range(first, first + N):
     env = dict(os.environ, LD_LIBRARY_PATH=os.environ.get('FAKE_DEVICE_DIR', '/tmp/fake'), SPUMONI_CACHE="off", SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_signal_unsafe=0:history_size=4",
                SPUMONI_SUPER_BATCH=str(int(rng.choice([1000, 2500, 10**7]))), SPUMONI_GPUS=",".join(["0"] * int(rng.integers(1, 4))))
     if rng.random() < 0.3: env["SPUMONI_HOST_FORMAT"] = "1"
-    flags = (["-c"] if rep else []) + (["-d"] if doc else [])
+    # the classifier's inputs: bin width (-w, 50 .. 400 or refused) and the null database's percentile (-> max_value_thr,
+    # compute_ms_pml.cpp:864-875 / 1054-1063)
+    bw = int(rng.choice([150, 50, 400, 77, 233, 49, 401]))
+    from tests.sdsl_files import write_null_db
+    pct = float(rng.choice([0.0, 1.0, 3.0, 4.0, 9.0, 17.5, 60.0, 250.0]))
+    for pf in {prefix, str(tmp / "promoted" / "ref.bin")}:
+        if os.path.exists(pf):
+            write_null_db(pf + ".pmlnulldb", pct, [1, 2, 3, 4]); write_null_db(pf + ".msnulldb", pct + 5, [5, 9, 9])
+    flags = (["-c"] if rep else []) + (["-d"] if doc else []) + (["-w", str(bw)] if bw != 150 else [])
     if rng.random() < 0.5: flags += ["-t", str(int(rng.integers(1, 9)))]  # (-t: the host threads that parse and format)
     # digestion (run -m / -a, compute_ms_pml.cpp:919-931): which index the digested reads are searched in does not matter
     # to the host; -m wants the index under <ref>.bin
@@ -88,8 +96,12 @@ for seed in range(first, first + N):
                     if f.startswith("ref.fa"):
                         shutil.copy(tmp / f, tmp / "promoted" / ("ref.bin" + f[len("ref.fa"):]))
     r = subprocess.run(PRE + [HOST, "run", "-r", ref_run, "-p", str(tmp / "cli" / "reads.fa"), "-" + digest, "-" + mode] + flags + kw, capture_output=True, env=env)
-    o = subprocess.run([T.ORC_RUN, pfx, str(tmp / "orc" / "reads.fa"), mode, str(doc), str(rep), "150", digest, prefix + ".rawtext"] + orc_kw, capture_output=True)
+    o = subprocess.run([T.ORC_RUN, pfx, str(tmp / "orc" / "reads.fa"), mode, str(doc), str(rep), str(bw), digest, prefix + ".rawtext"] + orc_kw, capture_output=True)
     problems = []; fatals += o.returncode != 0; empties += (len(data) == 0)
+    if bw < 50 or bw > 400:  # include/spumoni_main.hpp:318-320: refused before anything is read
+        if r.returncode != 1 or b"bin size used is not optimal" not in r.stderr:
+            bad += 1; print("seed", seed, "bin width", bw, "was not refused", r.returncode)
+        continue
     if b"Sanitizer" in r.stderr or b"runtime error" in r.stderr: problems.append("sanitizer")
     if (r.returncode == 0) != (o.returncode == 0): problems.append(f"rc {r.returncode} vs {o.returncode}")
     if o.returncode != 0:
