@@ -456,3 +456,34 @@ def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch
     for e in (".pseudo_lengths", ".report"):
         assert filecmp.cmp(str(tmp_path / "gpu" / "fatal.fa") + e, str(tmp_path / "orc" / "fatal.fa") + e, shallow=False), e
     assert os.path.getsize(str(tmp_path / "gpu" / "fatal.fa") + ".pseudo_lengths") == 0
+
+
+def _general_text_case(tmp_path, exe):
+    """`run -g -n`: the pattern file is raw bytes, every read ends in \x01 and is named read_<k>; no upper-casing; an empty
+    read has an empty values line; what follows the last separator is not a read (compute_ms_pml.cpp:1219-1297).  Both
+    modes against the oracle harness; returns the reference prefix."""
+    letters = [3, 4, 5, 60, 97, 127, 128, 129, 200, 255]
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 98, letters, n=4000, nreads=60)
+    parts = [seqs[offs[q]: offs[q + 1]].tobytes() for q in range(offs.size - 1)]
+    data = b"\x01".join(parts[:20]) + b"\x01\x01" + b"\x01".join(parts[20:40]) + b"\x01abc\x00def\x01" + b"trailing text without a separator"
+    for d in ("cli", "orc"):
+        (tmp_path / d).mkdir()
+        (tmp_path / d / "pattern.txt").write_bytes(data)
+    for mode, exts in (("P", (".pseudo_lengths",)), ("M", (".lengths", ".pointers"))):
+        env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", SPUMONI_SUPER_BATCH="1500")
+        r = subprocess.run([exe, "run", "-r", ref, "-p", str(tmp_path / "cli" / "pattern.txt"), "-n", "-g", "-" + mode], capture_output=True, env=env)
+        assert r.returncode == 0 and b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr.decode(errors="replace")[-3000:]
+        assert b"finished processing 42 reads" in r.stderr
+        o = subprocess.run([ORC_RUN, prefix, str(tmp_path / "orc" / "pattern.txt"), mode, "0", "0", "150", "g", prefix + ".rawtext"], capture_output=True)
+        assert o.returncode == 0, o.stderr.decode()
+        for e in exts:
+            a, b = str(tmp_path / "cli" / "pattern.txt") + e, str(tmp_path / "orc" / "pattern.txt") + e
+            assert os.path.getsize(b) > 10000 and filecmp.cmp(a, b, shallow=False), (mode, e)
+    return ref
+
+
+@pytest.mark.xfail(strict=False, reason="general-text mode had no test at all until the end of round 3; verified host side on the CPU "
+                                        "(tests/test_host_harness_cpu.py), expected to pass on the device; marked so that its first GPU "
+                                        "run cannot stop the suite")
+def test_cli_general_text_mode_on_the_device(built, tmp_path):
+    _general_text_case(tmp_path, HOST_BIN)

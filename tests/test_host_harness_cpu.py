@@ -192,29 +192,11 @@ def test_cli_differential_fuzz_against_the_oracle_harness(on_fake_device, tmp_pa
 
 
 def test_general_text_mode(on_fake_device, tmp_path):
-    """`run -g -n` (classify_general_reads_pml / _ms, compute_ms_pml.cpp:1219-1297): the pattern file is raw bytes, every
-    read ends in \\x01 and is named read_<k>; no upper-casing; an empty read has an empty values line; what follows the
-    last separator is not a read.  Bytes >= 128, a NUL, lower case, several super-batches -- PML and MS, the ASan build,
-    against the oracle harness."""
+    """`run -g -n` (classify_general_reads_pml / _ms, compute_ms_pml.cpp:1219-1297) through the ASan build against the oracle
+    harness: tests/test_gpu_cli.py::_general_text_case (bytes >= 128, a NUL, lower case, empty reads, trailing text,
+    several super-batches, PML and MS)."""
     T = _cli()
-    letters = [3, 4, 5, 60, 97, 127, 128, 129, 200, 255]
-    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 98, letters, n=4000, nreads=60)
-    parts = [seqs[offs[q]: offs[q + 1]].tobytes() for q in range(offs.size - 1)]
-    data = b"\x01".join(parts[:20]) + b"\x01\x01" + b"\x01".join(parts[20:40]) + b"\x01abc\x00def\x01" + b"trailing text without a separator"
-    for d in ("cli", "orc"):
-        (tmp_path / d).mkdir()
-        (tmp_path / d / "pattern.txt").write_bytes(data)
-    for mode, exts in (("P", (".pseudo_lengths",)), ("M", (".lengths", ".pointers"))):
-        env = dict(os.environ, SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", SPUMONI_SUPER_BATCH="1500")
-        r = subprocess.run([os.path.join(BIN, "spumoni_asan"), "run", "-r", ref, "-p", str(tmp_path / "cli" / "pattern.txt"), "-n", "-g", "-" + mode],
-                           capture_output=True, env=env)
-        assert r.returncode == 0 and b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr.decode(errors="replace")[-3000:]
-        assert b"finished processing 42 reads" in r.stderr
-        o = subprocess.run([T.ORC_RUN, prefix, str(tmp_path / "orc" / "pattern.txt"), mode, "0", "0", "150", "g", prefix + ".rawtext"], capture_output=True)
-        assert o.returncode == 0, o.stderr.decode()
-        for e in exts:
-            a, b = str(tmp_path / "cli" / "pattern.txt") + e, str(tmp_path / "orc" / "pattern.txt") + e
-            assert os.path.getsize(b) > 10000 and filecmp.cmp(a, b, shallow=False), (mode, e)
+    ref = T._general_text_case(tmp_path, os.path.join(BIN, "spumoni_asan"))
     # the option checks of include/spumoni_main.hpp:300-310
     for extra, msg in ((["-a"], b"minimizer digestion must be turned off"), (["-n", "-c"], b"classification is not available"),
                        (["-n", "-t", "2"], b"multi-threading is not available")):
