@@ -53,6 +53,7 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".inc", ".cpp", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt, os.path.join(dp, f)
+                assert "fake_device" not in txt and "fake_spumoni" not in txt, os.path.join(dp, f)  # (the CPU tier's stand-in: tests only)
 
 
 def test_header_is_plain_c(tmp_path):
@@ -67,3 +68,11 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     code = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "spumoni_gpu.h")).read(), flags=re.S)  # (comments cite them)
     assert "torch" not in code and "hipStream_t" not in code and "std::" not in code and "#include <hip" not in code
+
+
+def test_the_fake_device_stays_inside_the_tests():
+    """tests/fake_device (the C-ABI answered by the oracle, for the host's CPU tier) is test infrastructure: neither the
+    build entry point nor the benchmark knows of it."""
+    for f in ("__graft_entry__.py", "bench.py"):
+        txt = open(os.path.join(ROOT, f)).read()
+        assert "fake_device" not in txt and "fake_spumoni" not in txt, f
