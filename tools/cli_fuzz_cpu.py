@@ -19,7 +19,9 @@ HOST = os.path.join(ROOT, 'spumoni_amd', 'bin', os.environ.get('CLI_FUZZ_BIN', '
 PRE = ["setarch", "x86_64", "-R"] if HOST.endswith("_tsan") and shutil.which("setarch") else []  # (gcc 11's TSan wants ASLR off here)
 
 def rand_seq(rng, n):
-    if rng.random() < 0.6:
+    if n >= text.size - 1:
+        s = np.tile(text, n // text.size + 1)[:n].copy()   # (longer than the text: the text over and over)
+    elif rng.random() < 0.6:
         a = int(rng.integers(0, text.size - n - 1)); s = text[a:a + n].copy()
     else:
         s = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n)
@@ -38,6 +40,8 @@ def make_file(rng, hostile):
         elif u < 0.25 + 0.05 * hostile: name = b"x" * int(rng.integers(1, 3))   # short header (<= 2 chars with the mark -> fatal)
         elif u < 0.25 + 0.08 * hostile: name = b""                               # bare mark
         n = int(rng.choice([0, 1, 3, 20, 80, 150, 400, 1200], p=[0.04 * hostile, 0.06, 0.1, 0.2, 0.25 + 0.04 * (1 - hostile), 0.2, 0.1, 0.05]))
+        if rng.random() < 0.004: n = int(rng.integers(65530, 66000))   # a read that does not fit 16-bit values: the batch goes the 32-bit way
+        if rng.random() < 0.01: name += b" " + b"d" * int(rng.integers(200, 6000))   # a very long header line
         s = rand_seq(rng, n) if n else b""
         eol = b"\r\n" if rng.random() < 0.1 else b"\n"
         trail = b"  " if rng.random() < 0.1 else b""
