@@ -599,6 +599,17 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         DevBuf Sb, LFk;
         bool balance = want_balance;
         if (balance) {
+            // the passes want 45 B per run of scratch and a second copy of the run arrays (up to 50 B per run): an index
+            // that leaves no room for that is flattened without them rather than not at all
+            size_t mem_free = 0, mem_total = 0;
+            SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
+            if ((double)mem_free < 110.0 * (double)cur.r + (double)(256u << 20)) {
+                balance = false;
+                if (timing) fprintf(stderr, "[spx] pieces, pass %d: %.1f GB free, too little for the image pass over %llu rows: not balanced\n",
+                                    pass, (double)mem_free / 1e9, (unsigned long long)cur.r);
+            }
+        }
+        if (balance) {
             const int rc = images_of_runs(cur, Sb, LFk, balance, st);
             if (rc != SPX_OK) return rc;
         }
