@@ -68,3 +68,13 @@ def test_pin_tool_passes_and_fails(built_all, tmp_path):
     open(d / "ref.fa.bwt.len", "wb").write(bytes(lens))
     r = subprocess.run([sys.executable, TOOL, str(d)], capture_output=True, text=True)
     assert r.returncode == 1 and "differs in lens" in r.stdout
+
+
+def test_pin_tool_cli_leg_on_the_fake_device(built_all, fake_device, tmp_path):
+    """--gpu (check 3: the `spumoni run` binary on the same directory) goes through its mechanics on the CPU with
+    tests/fake_device behind the binary: six PASS lines (2 reader checks, 2 oracle runs, 2 CLI runs)."""
+    d = _make_dir(tmp_path)
+    env = dict(os.environ, LD_LIBRARY_PATH=fake_device + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), SPUMONI_CACHE="off")
+    r = subprocess.run([sys.executable, TOOL, str(d), "--gpu"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("[PASS]") == 6 and "[FAIL]" not in r.stdout, r.stdout
