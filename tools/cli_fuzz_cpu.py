@@ -5,13 +5,28 @@ the boundary or formatted on the host, PML / MS, with and without documents and 
 the oracle harness (oracle/orc_run): the same exit status, the same error message, the same bytes in every output file --
 also in the files a run that ends in a fatal error leaves behind.
 
-    python tools/cli_fuzz_cpu.py [seeds [first seed]]        (FAKE_DEVICE_DIR: where tests/fake_device was built as
-                                                              libspumoni_gpu.so, default /tmp/fake; see tools/host_stress.py)
+    python tools/cli_fuzz_cpu.py [seeds [first seed]]        (builds tests/fake_device and the sanitizer builds of the host if
+                                                              they are not there; FAKE_DEVICE_DIR: an existing build;
+                                                              CLI_FUZZ_BIN=spumoni_tsan | spumoni: another build of the host)
 """
-import os, sys, subprocess, pathlib, shutil, numpy as np, filecmp
+import os, sys, subprocess, pathlib, shutil, tempfile, numpy as np, filecmp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import test_gpu_cli as T
+
+def fake_device_dir():
+    """tests/fake_device built as libspumoni_gpu.so (FAKE_DEVICE_DIR: an existing build; otherwise built here, once)."""
+    d = os.environ.get("FAKE_DEVICE_DIR") or os.path.join(tempfile.gettempdir(), "spumoni_fake_device")
+    so = os.path.join(d, "libspumoni_gpu.so")
+    src = [os.path.join(ROOT, "tests", "fake_device", "fake_spumoni_gpu.c"), os.path.join(ROOT, "oracle", "spumoni_oracle.c"),
+           os.path.join(ROOT, "oracle", "orc_digest.c")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in src):
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsigned-char", "-fPIC", "-Wno-unknown-pragmas", "-shared", "-pthread", "-o", so] + src)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "spumoni_amd", "csrc", "host"), "all", "san", "-j2"], stdout=subprocess.DEVNULL)
+    return d
+
+FAKE = fake_device_dir()
 tmp = pathlib.Path(os.environ.get('CLI_FUZZ_DIR', '/tmp/cli_fuzz')); shutil.rmtree(tmp, ignore_errors=True); tmp.mkdir(parents=True)
 ref, prefix, seqs, offs, rng0 = T._setup(tmp, 97, list(b"ACGT"), n=8000, nreads=10)
 text = np.fromfile(prefix + ".rawtext", dtype=np.uint8)
@@ -72,7 +87,7 @@ for seed in range(first, first + N):
     for d in ("cli", "orc"):
         shutil.rmtree(tmp / d, ignore_errors=True); (tmp / d).mkdir()
         (tmp / d / "reads.fa").write_bytes(data)
-    env = dict(os.environ, LD_LIBRARY_PATH=os.environ.get('FAKE_DEVICE_DIR', '/tmp/fake'), SPUMONI_CACHE="off", SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_signal_unsafe=0:history_size=4",
+    env = dict(os.environ, LD_LIBRARY_PATH=FAKE, SPUMONI_CACHE="off", SPUMONI_TEXT=prefix + ".rawtext", ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_signal_unsafe=0:history_size=4",
                SPUMONI_SUPER_BATCH=str(int(rng.choice([1000, 2500, 10**7]))), SPUMONI_GPUS=",".join(["0"] * int(rng.integers(1, 4))))
     if rng.random() < 0.3: env["SPUMONI_HOST_FORMAT"] = "1"
     # the classifier's inputs: bin width (-w, 50 .. 400 or refused) and the null database's percentile (-> max_value_thr,

@@ -2,16 +2,28 @@
 reads cut into 260 .. 1 040 super-batches (SPUMONI_SUPER_BATCH) dealt to 2 .. 5 workers, text from the boundary and
 host-formatted, against tests/fake_device (the C-ABI answered by the CPU oracle; test infrastructure):
 
-    mkdir -p /tmp/fake && gcc -O1 -g -std=c11 -fsigned-char -fPIC -Wno-unknown-pragmas -shared -pthread \
-        -o /tmp/fake/libspumoni_gpu.so tests/fake_device/fake_spumoni_gpu.c oracle/spumoni_oracle.c oracle/orc_digest.c
-    make -C spumoni_amd/csrc/host all san && python tools/host_stress.py
+    python tools/host_stress.py        (builds tests/fake_device and the sanitizer builds of the host if they are not there)
 
 Every run must exit 0 without a sanitizer report and write the oracle harness's bytes (profiles/r03_host_stress_cpu.txt)."""
-import os, sys, subprocess, pathlib, shutil, numpy as np, glob, filecmp
-sys.path.insert(0, '/root/repo')
+import os, sys, subprocess, pathlib, shutil, tempfile, numpy as np, glob, filecmp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from tests import test_gpu_cli as T
+
+def fake_device_dir():
+    """tests/fake_device built as libspumoni_gpu.so (FAKE_DEVICE_DIR: an existing build; otherwise built here, once)."""
+    d = os.environ.get("FAKE_DEVICE_DIR") or os.path.join(tempfile.gettempdir(), "spumoni_fake_device")
+    so = os.path.join(d, "libspumoni_gpu.so")
+    src = [os.path.join(ROOT, "tests", "fake_device", "fake_spumoni_gpu.c"), os.path.join(ROOT, "oracle", "spumoni_oracle.c"),
+           os.path.join(ROOT, "oracle", "orc_digest.c")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in src):
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsigned-char", "-fPIC", "-Wno-unknown-pragmas", "-shared", "-pthread", "-o", so] + src)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "spumoni_amd", "csrc", "host"), "all", "san", "-j2"], stdout=subprocess.DEVNULL)
+    return d
+
 tmp = pathlib.Path('/tmp/stress'); shutil.rmtree(tmp, ignore_errors=True); tmp.mkdir()
-fake = os.environ.get('FAKE_DEVICE_DIR', '/tmp/fake')  # tests/fake_device built as libspumoni_gpu.so (see the docstring)
+fake = fake_device_dir()
 ref, prefix, seqs, offs, rng = T._setup(tmp, 95, list(b"ACGT"), n=20000, nreads=6000)
 T._write_fasta(tmp / "reads.fa", seqs, offs, np.random.default_rng(5))
 o = subprocess.run([T.ORC_RUN, prefix, str(tmp / "reads.fa"), "P", "1", "1", "150", "n", prefix + ".rawtext"], capture_output=True); assert o.returncode == 0
@@ -19,7 +31,7 @@ for e in (".pseudo_lengths", ".doc_numbers", ".report"): shutil.move(str(tmp / "
 bad = 0
 for rep in range(12):
     for which in ("tsan", "asan", ""):
-        exe = '/root/repo/spumoni_amd/bin/spumoni' + ("_" + which if which else "")
+        exe = os.path.join(ROOT, 'spumoni_amd', 'bin', 'spumoni') + ("_" + which if which else "")
         env = dict(os.environ, LD_LIBRARY_PATH=fake, SPUMONI_CACHE="off", SPUMONI_GPUS=",".join(["0"] * (2 + rep % 4)), SPUMONI_SUPER_BATCH=str(1000 + 700 * (rep % 5)),
                    TSAN_OPTIONS="report_signal_unsafe=0:history_size=4:exitcode=66", ASAN_OPTIONS="detect_leaks=0", SPUMONI_TEXT=prefix + ".rawtext")
         if rep % 3 == 2: env["SPUMONI_HOST_FORMAT"] = "1"
