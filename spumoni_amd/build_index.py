@@ -123,14 +123,15 @@ def null_reads_from_list(files_seqs, rng):
 
 def null_reads_from_fasta(seqs, rng):
     """The null reads of a single FASTA file (src/refbuilder.cpp:234-270): as above, but the sequences are read as
-    they are in the file (no upper-casing), a substring that contains 'N' is drawn and dropped, and reading stops with
-    the sequence that brings the count to 1000."""
+    they are in the file (no upper-casing), a substring that contains 'N' is drawn and dropped, and reading stops after
+    the sequence in which a sampled substring brings the count to 1000 (whole short sequences do not stop it)."""
     reads = []
+    go = True  # go_for_extraction (:247): only the sampling branch ever clears it -- sequences of at most 150 characters are
+    #            counted without touching it, so a file of many short sequences yields more than 1000 reads (ADVICE r3)
     for s in seqs:
-        if len(reads) >= NULL_READ_BOUND:
+        if not go:
             break
         grab = 25 if len(reads) >= NUM_NULL_READS else 100
-        go = True
         i = 0
         while i < grab and go and s.size > NULL_READ_CHUNK:
             at = rng.rand() % (s.size - NULL_READ_CHUNK)

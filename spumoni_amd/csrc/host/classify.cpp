@@ -132,14 +132,35 @@ void IndexSet::load(const RunOptions& o) {
     }
     ix.push_back(first);
     if (spx_index_stats(first, &n, &r) != SPX_OK) fatal_error("%s", spx_last_error());
-    for (size_t d = 1; d < o.devices.size(); ++d) {
+    // Replicas: flatten once, copy N - 1 times -- as a doubling tree (device 0 -> 1; 0 -> 2, 1 -> 3; 0 -> 4 ... 3 -> 7), the
+    // copies of a round on threads of their own: every copy has its own source and, on an xGMI node, its own link, so
+    // seven replicas of a 200 GB index cost three copy times instead of seven
+    const size_t ndev = o.devices.size();
+    const auto t_all = std::chrono::steady_clock::now();
+    ix.resize(std::max<size_t>(ndev, 1), nullptr);
+    for (size_t have = 1; have < ndev;) {
+        const size_t nnew = std::min(have, ndev - have);
         const auto t0 = std::chrono::steady_clock::now();
-        spx_index* p = spx_index_clone(first, o.devices[d]);
-        if (!p) fatal_error("%s", spx_last_error());
-        ix.push_back(p);
-        std::fprintf(stderr, "[timing] index replica on device %d (copied from device %d)  %.3f s\n", o.devices[d], dev0,
+        std::vector<std::string> errs(nnew);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nnew; ++i)
+            th.emplace_back([&, i] {
+                spx_index* p = spx_index_clone(ix[i], o.devices[have + i]);
+                if (!p) errs[i] = spx_last_error();
+                ix[have + i] = p;
+            });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < nnew; ++i) {
+            if (!ix[have + i]) fatal_error("%s", errs[i].c_str());
+            std::fprintf(stderr, "[timing] index replica on device %d (copied from device %d)\n", o.devices[have + i], o.devices[i]);
+        }
+        std::fprintf(stderr, "[timing] %zu replica%s in parallel  %.3f s\n", nnew, nnew > 1 ? "s" : "",
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        have += nnew;
     }
+    if (ndev > 1)
+        std::fprintf(stderr, "[timing] all %zu index replicas  %.3f s\n", ndev - 1,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count());
 }
 
 size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promotions, bool use_dna_letters) {
@@ -244,11 +265,10 @@ struct PinnedPool {
         std::lock_guard<std::mutex> g(mu);
         blocks.emplace_back(p, bytes);
     }
-    ~PinnedPool() {
-        for (auto& b : blocks) spx_host_free(b.first);
-    }
+    // (no destructor: blocks still here when the process ends stay page-locked until the system takes them back --
+    // unlocking them one by one at exit is the cost the slots avoid as well)
 };
-PinnedPool g_pinned_pool;
+PinnedPool& g_pinned_pool = *new PinnedPool;
 
 // grow-only buffer in page-locked host memory (spx_host_alloc): copies to and from the GPU
 // then run at PCIe DMA speed (171 vs 42 M reads/s through spx_query_batch on the bench shape)
@@ -448,9 +468,14 @@ struct OutFile {
         // (0.2 s for 2 GB on tmpfs, inside "processing the patterns").  It is moved aside and removed on a thread
         // of its own instead; the new file starts empty either way.
         struct stat st;
-        if (::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > (64 << 20)) {
+        // (lstat: a symbolic link is left alone and its target truncated as before; the old file is registered, so that an
+        // early exit removes it too)
+        if (::lstat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > (64 << 20)) {
             const std::string old = path + ".old." + std::to_string((long)::getpid());
-            if (::rename(path.c_str(), old.c_str()) == 0) std::thread([old] { ::unlink(old.c_str()); }).detach();
+            if (::rename(path.c_str(), old.c_str()) == 0) {
+                register_leftover(old);
+                std::thread([old] { ::unlink(old.c_str()); }).detach();
+            }
         }
         fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) fatal_error("cannot create %s", path.c_str());
@@ -633,35 +658,10 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
     size_t formatted = 0;
     bool placed = false;
     auto lo_of = [&](size_t t) { return nreads * t / nt; };
-    OutFile* const files[3] = {&out.lengths, &out.pointers, &out.docs};
     auto work = [&](size_t t) {
         TextChunk& c = chunks[t];
         const auto tf0 = std::chrono::steady_clock::now();
-        if (res.device_text) {
-            // the values lines are there already: drop the ">id\n" lines into their gaps, write the thread's stretch of
-            // every stream at its place behind the file's end, and format the report lines
-            const size_t lo = lo_of(t), hi = lo_of(t + 1);
-            for (int i = 0; i < 3; ++i) {
-                if (!(res.streams & (1u << i)) || !files[i]->is_open()) continue;
-                char* base = const_cast<char*>(res.text[i].data());
-                const uint64_t* ls = res.line_start[i].data();
-                for (size_t q = lo; q < hi; ++q) {
-                    char* p = base + ls[q];
-                    const std::string_view id = sb.ids[q];
-                    *p++ = '>';
-                    std::memcpy(p, id.data(), id.size());
-                    p[id.size()] = '\n';
-                }
-                if (hi > lo) files[i]->write_at(base + ls[lo], ls[hi] - ls[lo], files[i]->end + ls[lo]);
-            }
-            RunOptions ro = o;  // only the report is left to format
-            ro.use_doc = false;
-            ro.ms = false;
-            ro.report_only = true;
-            format_range(ro, sb, res, lo, hi, c);
-        } else {
-            format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
-        }
+        format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
         if (t == 0) g_format_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
         {
             std::unique_lock<std::mutex> g(mu);
@@ -682,10 +682,6 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
                 cv.wait(g, [&] { return placed; });
             }
         }
-        if (res.device_text) {
-            if (o.write_report && !c.report.empty()) out.report.write_at(c.report.data(), c.report.size(), at_r[t]);
-            return;
-        }
         if (c.tl.len) out.lengths.write_at(c.tl.buf.data(), c.tl.len, at_l[t]);
         if (o.ms && c.tp.len) out.pointers.write_at(c.tp.buf.data(), c.tp.len, at_p[t]);
         if (o.use_doc && c.td.len) out.docs.write_at(c.td.buf.data(), c.td.len, at_d[t]);
@@ -695,12 +691,6 @@ void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, cons
     for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
-    if (res.device_text) {
-        for (int i = 0; i < 3; ++i)
-            if ((res.streams & (1u << i)) && files[i]->is_open()) files[i]->end += res.line_start[i][nreads];
-        out.report.end = at_r[nt];
-        return;
-    }
     out.lengths.end = at_l[nt];
     out.pointers.end = at_p[nt];
     out.docs.end = at_d[nt];
@@ -908,16 +898,22 @@ private:
 // (per slot: the reads of a super-batch, and per output stream its text and its record offsets).
 void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
     if (spx_device_count() <= 0) return;
-    const size_t nslots = 2 * std::max<size_t>(ndev, 1) + 3;
+    // sized from the reads file, not from the super-batch limit alone: a small file needs small blocks and few
+    // slots, and below a megabyte locking pages ahead of time buys nothing
+    struct stat sb;
+    if (::stat(o.pattern_file.c_str(), &sb) != 0 || sb.st_size < (1 << 20)) return;
+    const size_t fsize = (size_t)sb.st_size;
+    const size_t batches = fsize / std::max<size_t>(o.super_batch_chars, 1) + 1;
+    const size_t nslots = std::min<size_t>(2 * std::max<size_t>(ndev, 1) + 3, batches + 1);
     const bool report_only = o.report_only && !o.ms && o.write_report;
-    const size_t chars = o.super_batch_chars + (4u << 20);
+    const size_t chars = std::min<size_t>(o.super_batch_chars, fsize) + std::min<size_t>(4u << 20, fsize / 8 + 4096);
     std::vector<size_t> sizes;
     for (size_t i = 0; i < nslots; ++i) {
         sizes.push_back(chars);  // reads
         if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
         const size_t reads_guess = chars / 100 + 4096;
         if (!report_only) {  // lengths: "<value> " is 2-4 bytes for most values
-            sizes.push_back(chars * 3 + (8u << 20));
+            sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.ms) {  // pointers: up to 13 digits

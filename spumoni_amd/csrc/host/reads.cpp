@@ -5,6 +5,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <mutex>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdarg>
@@ -22,7 +24,22 @@ namespace spumoni_host {
 // device workers are still at work: std::exit would run the static destructors -- the page-locked pool, the library's
 // own -- under their feet (found as a heap-use-after-free by the CPU fuzz, tools/cli_fuzz_cpu.py).  So: flush what is
 // buffered (the output files are written with pwrite and need nothing) and leave without them.
+// outputs of an earlier run that were moved aside to be removed in the background (classify.cpp, OutFile::open): whoever
+// ends the process first makes sure none of them stays behind
+static std::mutex g_leftover_mu;
+static std::vector<std::string> g_leftovers;
+void register_leftover(const std::string& path) {
+    std::lock_guard<std::mutex> g(g_leftover_mu);
+    g_leftovers.push_back(path);
+}
+void remove_leftovers() {
+    std::lock_guard<std::mutex> g(g_leftover_mu);
+    for (const auto& p : g_leftovers) (void)::unlink(p.c_str());  // (already gone: fine)
+    g_leftovers.clear();
+}
+
 [[noreturn]] static void leave(int code) {
+    remove_leftovers();
     std::cout.flush();
     std::fflush(nullptr);
     std::_Exit(code);

@@ -82,6 +82,8 @@ private:
 };
 
 // error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)
+void register_leftover(const std::string& path);  // a file to be gone when the process ends, however it ends
+void remove_leftovers();
 [[noreturn]] void fatal_error(const char* fmt, ...);
 [[noreturn]] void fatal_warning(const char* fmt, ...);
 

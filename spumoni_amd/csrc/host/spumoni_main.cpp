@@ -243,6 +243,7 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     FORCE_LOG(tag, "finished processing %d reads. results are saved in *.%s file.", (int)num_reads,
               o.ms ? "lengths" : "pseudo_lengths");
     std::cout << std::endl;
+    remove_leftovers();  // (a large output of an earlier run, moved aside when its name was taken: gone before we are)
     return 0;
 }
 

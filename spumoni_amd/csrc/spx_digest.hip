@@ -39,6 +39,7 @@ struct DigestArgs {
     uint32_t wsz;   // k-mers per window
     uint32_t ring;  // power of two >= wsz + 64
     uint32_t xm;    // LEX_XOR_MASK restricted to the 2k bits of a k-mer
+    uint32_t tpack;  // -m: the four character hashes T[A] | T[C] << 8 | T[G] << 16 | T[T] << 24
     uint8_t key_of_kmer[256];  // sort key of every k-mer code: the hash (-m) or code ^ xm (-a)
     uint64_t* counts;          // pass 0: counts[q + 1] = bytes read q digests to
     const uint64_t* out_offs;  // pass 1
@@ -144,199 +145,290 @@ __device__ __forceinline__ uint32_t byte_min8(uint64_t w) {
     return min(m & 0xffffu, m >> 16);
 }
 
-// FAST8: the window holds eight k-mers (the default k = 4, w = 11): steps whose four characters
-// are all ACGT and whose window is full take a path that updates the window four k-mers at a time
+// The default shape -- k = 4, a window of eight k-mers (w = 11) -- over a read that is all ACGT, FOUR CHARACTERS PER STEP
+// with every quantity packed in one register (round 4; the generic loop below spends ~30 instructions per character
+// and the kernel was bound by them: 80 % VALU utilisation, profiles/r04_digest_counters.txt):
+//   codes   t  = ((x >> 1) ^ (x >> 2)) & 0x03030303          the 2-bit codes of the four characters, one per byte
+//   valid      = v_perm(letters, t) == x                      the code spelled back is the character itself
+//   keys    -m   T[c_p] ^ rotl(T[c_p-1], 1) ^ rotl(T[c_p-2], 2) ^ rotl(T[c_p-3], 3): four v_perm lookups of the (rotated)
+//                character hashes by the codes and the codes of the one / two / three characters before (v_alignbyte)
+//           -a   (t | t1 << 2 | t2 << 4 | t3 << 6) ^ xm
+//   minima       the keys of even and odd positions in 16-bit halves (E, O); the minimum over the last 2, 4, 8 positions by
+//                doubling with v_pk_min_u16, "one position back" being the other register or a 16-bit funnel shift
+//   emits        minimum != minimum one position back, as a 4-bit mask; a 16-entry table of v_perm selectors packs the
+//                emitted bytes, which collect in a 64-bit register and leave four at a time
+// A lane that meets a character outside ACGT (or a shape other than k = 4, wsz = 8) takes the generic loop for its read.
+struct SwarState {
+    uint32_t tp, Op, AEp, AOp, BEp, BOp, COp;
+};
+
+__device__ __forceinline__ uint32_t promote4(uint32_t m) {  // x > 2 ? x : x + 3 on four bytes (src/spumoni.cpp:311)
+    const uint32_t ge3 = (m | ((m | 0x80808080u) - 0x03030303u)) & 0x80808080u;
+#ifdef SPX_EXP_NOPROMOTE
+    return m;
+#endif
+    const uint32_t lt = (ge3 ^ 0x80808080u) >> 7;  // 1 in every byte below 3
+    return m + lt + (lt << 1);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int sft = 32; sft > 0; sft >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, sft));
+    return v;
+}
+
 template <int KIND, bool FAST8>
 __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
     constexpr int PASS = 2;  // count + park the minimizer bytes at the read's input offset (see below)
     __shared__ uint4 tile16[TILE / 16 + 1];  // + slack for the last 4-byte read of a read
     __shared__ uint8_t lut[256];
+    __shared__ uint32_t s_sel[16];  // v_perm selectors that pack the bytes named by a 4-bit mask (0x0c: a zero byte)
     const uint8_t* const tile = reinterpret_cast<const uint8_t*>(tile16);
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < 256; i += 64) lut[i] = a.key_of_kmer[i];
+    if (lane < 16) {
+        uint32_t sel = 0x0c0c0c0cu, n = 0;
+        for (uint32_t j = 0; j < 4; ++j)
+            if ((lane >> j) & 1) {
+                sel = (sel & ~(0xffu << (8 * n))) | (j << (8 * n));
+                n++;
+            }
+        s_sel[lane] = sel;
+    }
     const uint32_t k = a.k, wsz = a.wsz;
     const uint32_t kmask = (1u << (2 * k)) - 1;
     const uint64_t hm = wsz >= 8 ? 0ull : (~0ull << (8 * wsz));  // window bytes that do not exist
     const uint64_t ngroups = (a.nreads + 63) / 64;
+    // -m: the character hashes rotated by 0 .. 3 (bytes A, C, G, T)
+    auto rot4 = [](uint32_t v, uint32_t r) {
+        return r ? (((v << r) & (0x01010101u * ((0xffu << r) & 0xffu))) | ((v >> (8 - r)) & (0x01010101u * (0xffu >> (8 - r))))) : v;
+    };
+#ifdef SPX_EXP_TABV
+    uint32_t T0 = a.tpack, R1 = rot4(a.tpack, 1), R2 = rot4(a.tpack, 2), R3 = rot4(a.tpack, 3);
+    asm volatile("v_mov_b32 %0, %0" : "+v"(T0));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(R1));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(R2));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(R3));
+#else
+    const uint32_t T0 = a.tpack, R1 = rot4(a.tpack, 1), R2 = rot4(a.tpack, 2), R3 = rot4(a.tpack, 3);
+#endif
+    const uint32_t xm4 = (a.xm & 0xffu) * 0x01010101u;
+    constexpr uint32_t FIRST = 10;  // the first reporting position of a read: k - 1 + wsz - 1
     for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const uint64_t rd = grp * 64 + lane;
         const bool live = rd < a.nreads;
         const uint64_t rbeg = a.offs[live ? rd : a.nreads];
         const uint64_t rend = a.offs[live ? rd + 1 : a.nreads];
         const uint64_t g0 = __shfl(rbeg, 0), g1 = __shfl(rend, 63);
-        // PASS 0 counts, PASS 1 writes the digest at its final place (out_offs), PASS 2 does both in one
-        // go: counts, and the minimizer bytes parked at the read's INPUT offset in a scratch buffer
-        // (k_digest_unstash moves them once the offsets are known) -- the reads are digested once
-        uint64_t ob = 0;
-        if (PASS == 2) ob = rbeg;
-        // the lane's walk state
-        uint32_t filled = 0, kmer = 0, cnt = 0, last = 0, acc = 0, nacc = 0;
-        bool have = false;
-        uint64_t win = 0, e = 0;
-        auto push_byte = [&](uint32_t v) {  // PASS 1: byte e of this read's digest
-            const uint64_t addr = ob + e;
-            acc |= v << (8 * (uint32_t)(addr & 3));
-            nacc++;
-            e++;
-            if (((addr + 1) & 3) == 0) {  // the aligned dword that holds addr is complete
-                if (nacc == 4) {
-                    *reinterpret_cast<uint32_t*>(a.out + (addr - 3)) = acc;
-                } else {  // its first bytes belong to the previous read
-                    for (uint32_t j = 4 - nacc; j < 4; ++j) a.out[addr - 3 + j] = (uint8_t)(acc >> (8 * j));
-                }
-                acc = 0;
-                nacc = 0;
-            }
-        };
-        auto push_bytes = [&](uint32_t q, uint32_t nq) {  // nq <= 4 bytes of the digest, packed low first
-            const uint64_t addr = ob + e;
-            const uint32_t fill = (uint32_t)(addr & 3);
-            const uint64_t comb = (uint64_t)acc | ((uint64_t)q << (8 * fill));
-            e += nq;
-            if (fill + nq >= 4) {  // the aligned dword that holds addr is complete
-                const uint32_t lo = (uint32_t)comb;
-                uint8_t* const d = a.out + (addr - fill);
-                if (nacc == fill) {
-                    *reinterpret_cast<uint32_t*>(d) = lo;
-                } else {  // its first bytes belong to the previous read
-                    for (uint32_t j = fill - nacc; j < 4; ++j) d[j] = (uint8_t)(lo >> (8 * j));
-                }
-                acc = (uint32_t)(comb >> 32);
-                nacc = fill + nq - 4;
-            } else {
-                acc = (uint32_t)comb;
-                nacc += nq;
-            }
-        };
-        for (uint64_t t0 = g0 & ~15ull; t0 < g1; t0 += TILE) {
-            __syncthreads();  // everybody is done with the previous tile (and the LUT is in place)
+        // the minimizer bytes are parked at the read's INPUT offset in a scratch buffer (k_digest_unstash moves them
+        // once the offsets are known) -- the reads are digested once
+        const uint64_t ob = rbeg;
+        uint64_t e = 0;
+        bool generic = !FAST8;
+        auto load_tile = [&](uint64_t t0) {
+            __syncthreads();  // everybody is done with the previous tile (and the tables are in place)
             const uint64_t tend = min(t0 + TILE, (g1 + 15) & ~15ull);
-            {  // all loads of the tile in flight before the first LDS write; slots past the
-               // end of the stretch re-read its first chunk (always a valid address) and are never used
-                uint4 v[TILE / 16 / 64];
-#pragma unroll
-                for (uint32_t j = 0; j < TILE / 16 / 64; ++j) {
-                    const uint64_t g = t0 + ((uint64_t)j * 64 + lane) * 16;
-                    v[j] = *reinterpret_cast<const uint4*>(a.seqs + (g < tend ? g : t0));
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < TILE / 16 / 64; ++j) tile16[j * 64 + lane] = v[j];
+            // all loads of the tile in flight before the first LDS write; slots past the
+            // end of the stretch re-read its first chunk (always a valid address) and are never used
+            // (eight loads in flight at a time: all sixteen cost 64 registers and, beside the packed walk's state, went
+            // through scratch memory)
+            constexpr uint32_t NB = 8;
+            const uint32_t span = (uint32_t)(tend - t0);
+            const uint8_t* const src = a.seqs + t0;
+#pragma unroll 1
+            for (uint32_t j0 = 0; j0 < TILE / 16 / 64; j0 += NB) {
+                // (named values, not an array: the array was left in scratch memory)
+                auto ld = [&](uint32_t j) {
+                    const uint32_t o = ((j0 + j) * 64 + lane) * 16;
+                    return *reinterpret_cast<const uint4*>(src + (o < span ? o : 0u));
+                };
+                const uint4 v0 = ld(0), v1 = ld(1), v2 = ld(2), v3 = ld(3), v4 = ld(4), v5 = ld(5), v6 = ld(6), v7 = ld(7);
+                uint4* const dst = tile16 + j0 * 64 + lane;
+                dst[0 * 64] = v0;
+                dst[1 * 64] = v1;
+                dst[2 * 64] = v2;
+                dst[3 * 64] = v3;
+                dst[4 * 64] = v4;
+                dst[5 * 64] = v5;
+                dst[6 * 64] = v6;
+                dst[7 * 64] = v7;
             }
             __syncthreads();
-            const uint64_t lo = max(rbeg, t0), hi = min(rend, t0 + TILE);
-            const uint32_t mine = hi > lo ? (uint32_t)(hi - lo) : 0;
-            const uint32_t off = (uint32_t)(lo - t0);  // only used when mine > 0
-            uint32_t longest = mine;
-            for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, s));
-            for (uint32_t s = 0; s < longest; s += 4) {
-                // four characters of this lane's read (bytes past `mine` are ignored below; the
-                // tile array is over-allocated so that the read stays inside LDS)
-                uint32_t w4 = 0;
-                if (s < mine) __builtin_memcpy(&w4, tile + off + s, 4);
-                if (FAST8) {
-                    bool regular = s + 4 <= mine && filled == k && cnt == 8 && have;
+        };
+        if (FAST8) {
+            // ---- four characters per step, everything packed (all-ACGT reads) ----
+            SwarState q{0, 0, 0, 0, 0, 0, 0};
+            uint64_t acc = 0;  // emitted bytes not yet stored, low byte first
+            uint32_t nacc = 0;
+            uint32_t bad = 0;
+            uint64_t cur = rbeg;  // the next character of this lane's read
+            const uint32_t len = (uint32_t)min<uint64_t>(rend - rbeg, 0xffffffffull);
+            // consecutive tiles overlap by 16 bytes: a lane takes whole steps only (but at its read's end), and the up
+            // to three characters it leaves behind at the end of a tile are in the next one
+            for (uint64_t t0 = g0 & ~15ull; t0 < g1; t0 += TILE - 16) {
+                load_tile(t0);
+                const uint64_t hi = min(rend, t0 + TILE);
+                const uint32_t avail = hi > cur ? (uint32_t)(hi - cur) : 0;
+                const uint32_t take = hi == rend ? avail : (avail & ~3u);
+                const uint32_t off = take ? (uint32_t)(cur - t0) : 0;
+                const uint32_t pos0 = (uint32_t)(cur - rbeg);
+                const uint32_t nst = (take + 3) >> 2;
+                // a lane with nothing to do in this tile goes through the common steps like the others, on whatever bytes,
+                // with its results masked away (vm) and its state put back afterwards
+                const uint32_t vm = nst ? 0xffffffffu : 0u;
+                const SwarState q_before = q;
+                auto step = [&](uint32_t st) {
+                    uint32_t x;
+                    __builtin_memcpy(&x, tile + off + 4 * st, 4);
+                    const uint32_t pos = pos0 + 4 * st;
+                    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+                    const uint32_t inval = __builtin_amdgcn_perm(0x54474341u, 0x54474341u, t) ^ x;
+                    const uint32_t t1 = __builtin_amdgcn_alignbyte(t, q.tp, 3), t2 = __builtin_amdgcn_alignbyte(t, q.tp, 2),
+                                   t3 = __builtin_amdgcn_alignbyte(t, q.tp, 1);
+                    q.tp = t;
+                    uint32_t key;
+#ifdef SPX_EXP_DNAKEY
+                    if (false)
+#else
+                    if (KIND == SPX_DIGEST_PROMOTED)
+#endif
+                        key = __builtin_amdgcn_perm(T0, T0, t) ^ __builtin_amdgcn_perm(R1, R1, t1) ^
+                              __builtin_amdgcn_perm(R2, R2, t2) ^ __builtin_amdgcn_perm(R3, R3, t3);
+                    else
+                        key = (t | (t1 << 2) | (t2 << 4) | (t3 << 6)) ^ xm4;
+                    const uint32_t E = key & 0x00ff00ffu, O = (key >> 8) & 0x00ff00ffu;
+                    const uint32_t AE = pk_min_u16(E, __builtin_amdgcn_alignbit(O, q.Op, 16)), AO = pk_min_u16(O, E);
+                    const uint32_t BE = pk_min_u16(AE, __builtin_amdgcn_alignbit(AE, q.AEp, 16)),
+                                   BO = pk_min_u16(AO, __builtin_amdgcn_alignbit(AO, q.AOp, 16));
+                    const uint32_t CE = pk_min_u16(BE, q.BEp), CO = pk_min_u16(BO, q.BOp);
+                    const uint32_t XE = CE ^ __builtin_amdgcn_alignbit(CO, q.COp, 16), XO = CO ^ CE;
+                    q.Op = O;
+                    q.AEp = AE;
+                    q.AOp = AO;
+                    q.BEp = BE;
+                    q.BOp = BO;
+                    q.COp = CO;
+                    const uint32_t FE = ((XE + 0x00ff00ffu) >> 8) & 0x00010001u, FO = ((XO + 0x00ff00ffu) >> 8) & 0x00010001u;
+                    const uint32_t f = FE | (FO << 1);
+                    uint32_t idx = (f | (f >> 14)) & 0xfu;
+                    // positions that report: FIRST .. len - 1; the first report is always kept (:300 / :329)
+                    if (__builtin_amdgcn_ballot_w64(vm != 0 && (pos < FIRST + 2 || pos + 4 > len)) != 0) {  // (rare, and then for the whole wavefront)
+                        const int32_t lo = (int32_t)FIRST - (int32_t)pos, hiq = (int32_t)len - (int32_t)pos;
+                        const uint32_t l4 = lo < 0 ? 0u : (lo > 4 ? 4u : (uint32_t)lo), h4 = hiq < 0 ? 0u : (hiq > 4 ? 4u : (uint32_t)hiq);
+                        const uint32_t pm = h4 > l4 ? ((1u << h4) - (1u << l4)) : 0u;
+                        idx = (idx & pm) | ((lo >= 0 && lo < 4 && (uint32_t)lo < h4) ? (1u << lo) : 0u);
+                        bad |= (h4 >= 4 ? inval : (inval & ((1u << (8 * h4)) - 1u))) & vm;
+                    } else {
+                        bad |= inval & vm;
+                    }
+                    idx &= vm;
+                    const uint32_t vals = CE | (CO << 8);
+                    const uint32_t sel = s_sel[idx];
+                    const uint32_t comp = __builtin_amdgcn_perm(vals, vals, sel);
+                    acc |= (uint64_t)comp << (8 * nacc);
+                    nacc += (uint32_t)__popc(idx);
+                    if (nacc >= 4) {
+                        const uint32_t w4 = KIND == SPX_DIGEST_PROMOTED ? promote4((uint32_t)acc) : (uint32_t)acc;
+#ifdef SPX_EXP_DIGEST_NOSTORE
+                        if (w4 == 0x12345678u)
+#endif
+                        __builtin_memcpy(a.out + ob + e, &w4, 4);
+                        acc >>= 32;
+                        nacc -= 4;
+                        e += 4;
+                    }
+                };
+                // the steps every lane takes run without a predicate (reads of one length: all of them) ...
+                uint32_t nst_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(nst ? nst : 0xffffffffu));
+                if (nst_all == 0xffffffffu) nst_all = 0;
+                for (uint32_t st = 0; st < nst_all; ++st) step(st);
+                if (!vm) q = q_before;
+                // ... the rest lane by lane
+                for (uint32_t st = nst_all; __builtin_amdgcn_ballot_w64(st < nst) != 0; ++st)
+                    if (st < nst) step(st);
+                cur += take;
+            }
+            const uint32_t wt = KIND == SPX_DIGEST_PROMOTED ? promote4((uint32_t)acc) : (uint32_t)acc;
+            if (!bad)
+                for (uint32_t j = 0; j < nacc; ++j) a.out[ob + e + j] = (uint8_t)(wt >> (8 * j));
+            e += nacc;
+            generic = bad != 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(generic) != 0) {
+            // ---- the generic loop: any k <= 4, any window of at most eight k-mers, any characters ----
+            // the lane's walk state
+            uint32_t filled = 0, kmer = 0, cnt = 0, last = 0, acc = 0, nacc = 0;
+            bool have = false;
+            uint64_t win = 0;
+            if (generic) e = 0;
+            auto push_byte = [&](uint32_t v) {  // byte e of this read's digest
+                const uint64_t addr = ob + e;
+                acc |= v << (8 * (uint32_t)(addr & 3));
+                nacc++;
+                e++;
+                if (((addr + 1) & 3) == 0) {  // the aligned dword that holds addr is complete
+                    if (nacc == 4) {
+                        *reinterpret_cast<uint32_t*>(a.out + (addr - 3)) = acc;
+                    } else {  // its first bytes belong to the previous read
+                        for (uint32_t j = 4 - nacc; j < 4; ++j) a.out[addr - 3 + j] = (uint8_t)(acc >> (8 * j));
+                    }
+                    acc = 0;
+                    nacc = 0;
+                }
+            };
+            for (uint64_t t0 = g0 & ~15ull; t0 < g1; t0 += TILE) {
+                load_tile(t0);
+                const uint64_t lo = max(rbeg, t0), hi = min(rend, t0 + TILE);
+                const uint32_t mine = (generic && hi > lo) ? (uint32_t)(hi - lo) : 0;
+                const uint32_t off = (uint32_t)(lo - t0);  // only used when mine > 0
+                for (uint32_t s = 0; __builtin_amdgcn_ballot_w64(s < mine) != 0; s += 4) {
+                    // four characters of this lane's read (bytes past `mine` are ignored below; the
+                    // tile array is over-allocated so that the read stays inside LDS)
+                    uint32_t w4 = 0;
+                    if (s < mine) __builtin_memcpy(&w4, tile + off + s, 4);
+                    uint32_t kmers[4], keys[4];
+                    bool act[4], has[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t d = ((w4 >> (8 * j)) & 0xffu) - 'A';
-                        regular = regular && d < 20 && ((0x80045u >> d) & 1);  // A C G T
+                        const uint32_t ch = (w4 >> (8 * j)) & 0xffu;
+                        act[j] = s + j < mine;
+                        const uint32_t d = ch - 'A';
+                        const bool valid = d < 20 && ((0x80045u >> d) & 1);  // A C G T
+                        const uint32_t nf = valid ? min(filled + 1, k) : 0;
+                        filled = act[j] ? nf : filled;
+                        const uint32_t nk = ((kmer << 2) | (((ch >> 1) ^ (ch >> 2)) & 3)) & kmask;  // A0 C1 G2 T3
+                        kmer = act[j] ? nk : kmer;
+                        kmers[j] = kmer;
+                        has[j] = act[j] && filled == k;
                     }
-                    if (regular) {
-                        // the four k-mers ending at these characters, their keys
-                        const uint32_t t4 = ((w4 >> 1) ^ (w4 >> 2)) & 0x03030303u;  // codes, first character low
-                        const uint32_t c8 = (t4 * 0x40100401u) >> 24;               // c0<<6 | c1<<4 | c2<<2 | c3
-                        const uint32_t x = (kmer << 8) | c8;
-                        const uint32_t km0 = (x >> 6) & kmask, km1 = (x >> 4) & kmask, km2 = (x >> 2) & kmask;
-                        kmer = x & kmask;
-                        uint32_t q0, q1, q2, q3;
-                        if (KIND == SPX_DIGEST_PROMOTED) {
-                            q0 = lut[km0];
-                            q1 = lut[km1];
-                            q2 = lut[km2];
-                            q3 = lut[kmer];
-                        } else {
-                            q0 = km0 ^ a.xm;
-                            q1 = km1 ^ a.xm;
-                            q2 = km2 ^ a.xm;
-                            q3 = kmer ^ a.xm;
-                        }
-                        // minima of the four windows: old keys b0 (newest) .. b6, new keys q0 .. q3
-                        const uint32_t wl = (uint32_t)win, wh = (uint32_t)(win >> 32);
-                        const uint32_t p1 = min(wl & 0xffu, (wl >> 8) & 0xffu);
-                        const uint32_t p2 = min(p1, (wl >> 16) & 0xffu);
-                        const uint32_t p3 = min(p2, wl >> 24);
-                        const uint32_t p4 = min(p3, wh & 0xffu);
-                        const uint32_t p5 = min(p4, (wh >> 8) & 0xffu);
-                        const uint32_t p6 = min(p5, (wh >> 16) & 0xffu);
-                        const uint32_t n1 = min(q0, q1), n2 = min(n1, q2), n3 = min(n2, q3);
-                        const uint32_t m0 = min(q0, p6), m1 = min(n1, p5), m2 = min(n2, p4), m3 = min(n3, p3);
-                        win = (win << 32) | ((uint64_t)q0 << 24) | (q1 << 16) | (q2 << 8) | q3;
-                        // what the caller's lambda keeps (:305 / :333), in order
-                        const bool e0 = m0 != last, e1 = m1 != m0, e2 = m2 != m1, e3 = m3 != m2;
-                        last = m3;
-                        const uint32_t v0 = (KIND == SPX_DIGEST_PROMOTED && m0 <= 2) ? m0 + 3 : m0;
-                        const uint32_t v1 = (KIND == SPX_DIGEST_PROMOTED && m1 <= 2) ? m1 + 3 : m1;
-                        const uint32_t v2 = (KIND == SPX_DIGEST_PROMOTED && m2 <= 2) ? m2 + 3 : m2;
-                        const uint32_t v3 = (KIND == SPX_DIGEST_PROMOTED && m3 <= 2) ? m3 + 3 : m3;
-                        uint32_t q = e0 ? v0 : 0, nq = e0 ? 1 : 0;
-                        q |= e1 ? v1 << (8 * nq) : 0;
-                        nq += e1 ? 1 : 0;
-                        q |= e2 ? v2 << (8 * nq) : 0;
-                        nq += e2 ? 1 : 0;
-                        q |= e3 ? v3 << (8 * nq) : 0;
-                        nq += e3 ? 1 : 0;
-                        if (nq) push_bytes(q, nq);
-                        continue;
-                    }
-                }
-                uint32_t kmers[4], keys[4];
-                bool act[4], has[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t ch = (w4 >> (8 * j)) & 0xffu;
-                    act[j] = s + j < mine;
-                    const uint32_t d = ch - 'A';
-                    const bool valid = d < 20 && ((0x80045u >> d) & 1);  // A C G T
-                    const uint32_t nf = valid ? min(filled + 1, k) : 0;
-                    filled = act[j] ? nf : filled;
-                    const uint32_t nk = ((kmer << 2) | (((ch >> 1) ^ (ch >> 2)) & 3)) & kmask;  // A0 C1 G2 T3
-                    kmer = act[j] ? nk : kmer;
-                    kmers[j] = kmer;
-                    has[j] = act[j] && filled == k;
-                }
+                    for (int j = 0; j < 4; ++j)
+                        keys[j] = KIND == SPX_DIGEST_PROMOTED ? (uint32_t)lut[kmers[j]] : (kmers[j] ^ a.xm);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    keys[j] = KIND == SPX_DIGEST_PROMOTED ? (uint32_t)lut[kmers[j]] : (kmers[j] ^ a.xm);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    win = has[j] ? ((win << 8) | keys[j]) : win;
-                    cnt = has[j] ? min(cnt + 1, wsz) : cnt;
-                    const uint32_t mn = byte_min8(win | hm);
-                    const bool em = has[j] && cnt == wsz && (!have || mn != last);
-                    last = em ? mn : last;
-                    have = have || em;
-                    if (PASS == 0) {
-                        e += em ? 1 : 0;
-                    } else if (em) {
-                        if (KIND == SPX_DIGEST_PROMOTED) {
-                            push_byte(mn > 2 ? mn : mn + 3);
-                        } else if (PASS == 2) {
-                            push_byte(mn);  // one byte per minimizer; spelled out by k_digest_unstash
-                        } else {
-                            const uint32_t code_min = mn ^ a.xm;
-                            for (uint32_t t = 0; t < k; ++t)
-                                push_byte(letter_of((code_min >> (2 * (k - 1 - t))) & 3));
+                    for (int j = 0; j < 4; ++j) {
+                        win = has[j] ? ((win << 8) | keys[j]) : win;
+                        cnt = has[j] ? min(cnt + 1, wsz) : cnt;
+                        const uint32_t mn = byte_min8(win | hm);
+                        const bool em = has[j] && cnt == wsz && (!have || mn != last);
+                        last = em ? mn : last;
+                        have = have || em;
+                        if (em) {
+                            if (KIND == SPX_DIGEST_PROMOTED)
+                                push_byte(mn > 2 ? mn : mn + 3);
+                            else
+                                push_byte(mn);  // one byte per minimizer; spelled out by k_digest_unstash
                         }
                     }
                 }
             }
-        }
-        if (PASS >= 1) {
-            for (uint32_t j = 0; j < nacc; ++j) {
-                const uint64_t addr = ob + e - nacc + j;
-                a.out[addr] = (uint8_t)(acc >> (8 * (uint32_t)(addr & 3)));
+            if (generic) {
+                for (uint32_t j = 0; j < nacc; ++j) {
+                    const uint64_t addr = ob + e - nacc + j;
+                    a.out[addr] = (uint8_t)(acc >> (8 * (uint32_t)(addr & 3)));
+                }
             }
         }
-        if (PASS != 1 && live) a.counts[rd + 1] = e * (KIND == SPX_DIGEST_DNA ? k : 1);
+        (void)PASS;
+        if (live) a.counts[rd + 1] = e * (KIND == SPX_DIGEST_DNA ? k : 1);
     }
 }
 
@@ -472,6 +564,8 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
             a.key_of_kmer[code] = h;
         }
     }
+    a.tpack = (uint32_t)ix->charhash[0] | ((uint32_t)ix->charhash[1] << 8) | ((uint32_t)ix->charhash[2] << 16) |
+              ((uint32_t)ix->charhash[3] << 24);
     a.counts = d_out_offs;
     a.out_offs = d_out_offs;
     a.out = d_out;
@@ -505,10 +599,10 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
         a.out = stash;
         if (kind == SPX_DIGEST_PROMOTED)
-            a.wsz == 8 ? k_digest_lanes<SPX_DIGEST_PROMOTED, true><<<grid, 64, 0, st>>>(a)
+            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_PROMOTED, true><<<grid, 64, 0, st>>>(a)
                        : k_digest_lanes<SPX_DIGEST_PROMOTED, false><<<grid, 64, 0, st>>>(a);
         else
-            a.wsz == 8 ? k_digest_lanes<SPX_DIGEST_DNA, true><<<grid, 64, 0, st>>>(a)
+            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_DNA, true><<<grid, 64, 0, st>>>(a)
                        : k_digest_lanes<SPX_DIGEST_DNA, false><<<grid, 64, 0, st>>>(a);
         SPX_HIP(hipGetLastError());
         int rc = scan_counts();

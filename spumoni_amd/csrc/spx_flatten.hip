@@ -423,22 +423,27 @@ __device__ __forceinline__ void image_of(const uint64_t* S, const uint64_t* LFk,
     nb = run_of_position(S, r, lf + len - 1) - a;
 }
 
-__global__ void k_piece_count(const uint64_t* lens, const uint64_t* thr, uint64_t r, const uint64_t* S, const uint64_t* LFk,
-                              uint32_t span, uint32_t* pieces, unsigned long long* zero_thr, unsigned long long* span_max) {
+// zero_thr counts the zero thresholds of runs that are NOT their letter's first (a count over all runs held
+// against the number of letters balances out when one letter's first run has a threshold and another's later run has none)
+__global__ void k_piece_count(const uint8_t* heads, const uint64_t* lens, const uint64_t* thr, uint64_t r, const uint64_t* S,
+                              const uint64_t* LFk, uint32_t span, const uint32_t* first_of_letter, uint32_t* pieces,
+                              unsigned long long* zero_thr, unsigned long long* span_max) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (k >= r) return;
     uint64_t lf, a, nb;
     image_of(S, LFk, r, k, lens[k], lf, a, nb);
     pieces[k] = for_each_piece(lens[k], lf, S, a, nb, span, PieceCounter{});
-    if (thr[k] == 0) atomicAdd(zero_thr, 1ull);
+    const uint32_t h = heads[k] <= 1 ? 1 : heads[k];
+    if (thr[k] == 0 && first_of_letter[h] != (uint32_t)k) atomicAdd(zero_thr, 1ull);
     if (S && nb + 1 > span) atomicMax(span_max, (unsigned long long)(nb + 1));
 }
 
-__global__ void k_letters_present(const uint8_t* heads, uint64_t r, unsigned int* present) {
+__global__ void k_first_of_letter(const uint8_t* heads, uint64_t r, uint32_t* first_of_letter) {
     const uint64_t k = blockIdx.x * (uint64_t)TPB + threadIdx.x;
     if (k >= r) return;
     const uint32_t h = heads[k] <= 1 ? 1 : heads[k];
-    atomicOr(&present[h >> 5], 1u << (h & 31));
+    // (the plain read first: once the early runs have been through, hardly any run still has to use the atomic)
+    if ((uint32_t)k < __builtin_nontemporal_load(&first_of_letter[h])) atomicMin(&first_of_letter[h], (uint32_t)k);
 }
 
 struct PieceWriter {
@@ -623,27 +628,24 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         SPX_HIP(pieces.alloc((rc_ + 1) * 4));
         SPX_HIP(first_piece.alloc((rc_ + 1) * 4));
         SPX_HIP(cnt.alloc(16));
-        SPX_HIP(present.alloc(8 * 4));
+        SPX_HIP(present.alloc(256 * 4));
         SPX_HIP(hipMemsetAsync(cnt.p, 0, 16, st));
-        SPX_HIP(hipMemsetAsync(present.p, 0, 32, st));
+        SPX_HIP(hipMemsetAsync(present.p, 0xff, 256 * 4, st));
         SPX_HIP(hipMemsetAsync(pieces.as<uint32_t>() + rc_, 0, 4, st));
-        k_piece_count<<<nblocks(rc_), TPB, 0, st>>>(cur.lens, cur.thr, rc_, d_S, d_LFk, balance ? span : 0, pieces.as<uint32_t>(),
-                                                     cnt.as<unsigned long long>(), cnt.as<unsigned long long>() + 1);
-        k_letters_present<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, rc_, present.as<unsigned int>());
+        k_first_of_letter<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, rc_, present.as<uint32_t>());
+        k_piece_count<<<nblocks(rc_), TPB, 0, st>>>(cur.heads, cur.lens, cur.thr, rc_, d_S, d_LFk, balance ? span : 0,
+                                                     present.as<uint32_t>(), pieces.as<uint32_t>(), cnt.as<unsigned long long>(),
+                                                     cnt.as<unsigned long long>() + 1);
         size_t tb = 0;
         SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), rc_ + 1, st));
         SPX_HIP(tmp.alloc(tb + 256));
         SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, pieces.as<uint32_t>(), first_piece.as<uint32_t>(), rc_ + 1, st));
         unsigned long long zero_thr = 0, span_max = 0;
-        unsigned int pres[8];
         uint32_t r2_32 = 0;
         SPX_HIP(hipMemcpyAsync(&zero_thr, cnt.p, 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&span_max, cnt.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipMemcpyAsync(pres, present.p, 32, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&r2_32, first_piece.as<uint32_t>() + rc_, 4, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipStreamSynchronize(st));
-        unsigned nletters = 0;
-        for (unsigned v : pres) nletters += (unsigned)__builtin_popcount(v);
         const uint64_t r2 = r2_32;
         if (timing)
             fprintf(stderr, "[spx] pieces, pass %d: %llu rows -> %llu%s; longest image %llu runs (0: none over %u), longest run %llu; %.3f s\n",
@@ -651,7 +653,7 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
                     now() - t_pass);
         // a non-first run with a zero threshold (thr_bv skips stored values: inserted pieces would shift which one a
         // later run reads) / too many pieces: the run list stays as it is (the first pass: as the caller gave it)
-        if (zero_thr > nletters || r2 > 0xfffffff0ull || r2 < rc_) {
+        if (zero_thr > 0 || r2 > 0xfffffff0ull || r2 < rc_) {
             if (pass == 0) return as_it_is();
             break;
         }

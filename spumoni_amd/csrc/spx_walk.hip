@@ -1126,7 +1126,11 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     // variants that also fetch the aux record per jump like 20 too (MS+doc 27.6 / 28.0 / 28.4,
     // PML+doc 30.3 / 32.2 / 33.0).
     int occ = ix->occ_blocks[slot];
-    const int auto_waves = ix->view.nletters > 16 ? 20 : 16;
+    // Round 4, k_walk_fast (tools/ab.sh --waves-per-cu, profiles/r04_occupancy.txt): the headline batch 924 / 977 / 946 M
+    // reads/s at 12 / 16 / 20; the 1.25 M-read share of an 8-GPU strong cut 1.375 / 1.396 / 1.448 ms; the variants with
+    // document ids or MS pointers (whose LDS staging allows 12 at most for MS) 7.5 / 8.1 / 7.9 ms at 12 / 16 / 20.
+    constexpr bool SIDE = (MODE == SPX_MODE_MS) || DOC;
+    const int auto_waves = ix->view.nletters > 16 ? (fast ? (SIDE ? 12 : 16) : 20) : (fast && SIDE ? 12 : 16);
     const int target_waves = ix->waves_per_cu > 0 ? ix->waves_per_cu : auto_waves;
     int want = target_waves / (WALK_TPB / 64);
     if (want < 1) want = 1;

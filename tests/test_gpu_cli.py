@@ -424,9 +424,6 @@ def test_stale_cache_is_not_used(tmp_path):
     assert third == fresh and third != first
 
 
-@pytest.mark.xfail(strict=False, reason="written when round 3's GPU minutes were spent: its host side is verified on the CPU "
-                                        "(tests/test_host_harness_cpu.py, against tests/fake_device) and it is expected to pass on the "
-                                        "device; marked so that a surprise on its first GPU run cannot stop the suite")
 def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch):
     """SPUMONI_SUPER_BATCH=3000 characters and SPUMONI_GPUS=0,0: some twenty super-batches through two workers (two index
     replicas on one device), the ordered writer and the report thread, text from the device and formatted on the host:
@@ -458,6 +455,24 @@ def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch
     assert os.path.getsize(str(tmp_path / "gpu" / "fatal.fa") + ".pseudo_lengths") == 0
 
 
+def test_cli_four_workers_on_many_small_super_batches(built, tmp_path, monkeypatch):
+    """SPUMONI_GPUS=0,0,0,0: the index cloned as a doubling tree (0 -> 1, then 0 -> 2 and 1 -> 3 side by side), four
+    workers pulling some forty super-batches of 1500 characters from one queue, the ordered writer putting them back in
+    input order: the oracle harness's bytes in every file, every super-batch accounted for by exactly one worker, and more
+    than one worker doing the work (reads are independent: compute_ms_pml.cpp:890-1024)."""
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "1500")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0,0,0")
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 57, list(b"ACGT"), nreads=500)
+    for mode, extra in (("-P", ["-c", "-d", "-w", "50"]), ("-M", ["-c", "-d", "-w", "60"])):
+        r = _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, extra, mode)
+        err = r.stderr.decode()
+        batches = [int(ln.split("(")[1].split()[0]) for ln in err.splitlines() if "super-batches" in ln]
+        assert len(batches) == 4 and sum(batches) >= 30, batches
+        assert sum(1 for b in batches if b > 0) >= 2, batches
+        assert err.count("index replica on device 0") == 3 and "all 3 index replicas" in err, err[-2000:]
+        assert "2 replicas in parallel" in err
+
+
 def _general_text_case(tmp_path, exe):
     """`run -g -n`: the pattern file is raw bytes, every read ends in \x01 and is named read_<k>; no upper-casing; an empty
     read has an empty values line; what follows the last separator is not a read (compute_ms_pml.cpp:1219-1297).  Both
@@ -482,8 +497,5 @@ def _general_text_case(tmp_path, exe):
     return ref
 
 
-@pytest.mark.xfail(strict=False, reason="general-text mode had no test at all until the end of round 3; verified host side on the CPU "
-                                        "(tests/test_host_harness_cpu.py), expected to pass on the device; marked so that its first GPU "
-                                        "run cannot stop the suite")
 def test_cli_general_text_mode_on_the_device(built, tmp_path):
     _general_text_case(tmp_path, HOST_BIN)

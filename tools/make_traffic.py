@@ -35,6 +35,7 @@ assert fetch is not None and write is not None, "no k_walk dispatches in the PMC
 tj = {
     "key": b["roofline"]["traffic_key"],
     "hbm_bytes_per_launch": int(2 * fetch * 1024 + write * 1024),
+    "line_fills_per_launch": int(rd) if rd else None,  # TCC_EA0_RDREQ: 128-byte lines read out of HBM
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh), mean over {nf} "
               f"k_walk_fast (k_walk_lanes + k_expand_lengths where the state machine runs) dispatches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`: "
               f"FETCH_SIZE {fetch:.4g} KB (x2: gfx950 counts a 128-B line fill as 64 B), WRITE_SIZE {write:.4g} KB"
