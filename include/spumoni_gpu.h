@@ -279,9 +279,32 @@ int spx_digest_query_batch(spx_index *ix, int mode, int kind, uint32_t k, uint32
                            uint64_t *out_offsets, uint64_t out_capacity, uint32_t *out_lengths,
                            uint64_t *out_pointers, uint32_t *out_docs, spx_class *out_class,
                            uint64_t bin_width, uint64_t max_value_thr);
+/* The same with everything resident in device memory, asynchronous on `stream`:
+ * the batch form of "digest the read, then matching_statistics" (compute_ms_pml.cpp:919-938, the body of the harness
+ * loop under `run -m` / `run -a`) for reads that are already in HBM.  d_seqs / d_offsets as for
+ * spx_digest_batch_device; d_digested (digested_capacity >= spx_digest_capacity() bytes) is working memory that holds
+ * the digested reads afterwards -- concatenated at d_out_offsets, or, when the library chose to skip that pass, still
+ * where the digestion parked them (read q's minimizers at d_digested[d_offsets[q] ..]): only d_out_offsets and the
+ * outputs are the contract.  d_out_offsets (nreads + 1) receives the digested reads' offsets and every output is laid
+ * out at THOSE offsets; size the outputs for total_chars entries (a read digests to at most its length).  Outputs
+ * as for spx_query_batch_device / spx_query_batch_device16.                                                       */
+int spx_digest_query_batch_device(spx_index *ix, int mode, int kind, uint32_t k, uint32_t w,
+                                  const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t nreads,
+                                  uint64_t total_chars, uint8_t *d_digested, uint64_t digested_capacity,
+                                  uint64_t *d_out_offsets, uint32_t *d_out_lengths, uint64_t *d_out_pointers,
+                                  uint32_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                                  uint64_t max_value_thr, void *stream);
+int spx_digest_query_batch_device16(spx_index *ix, int mode, int kind, uint32_t k, uint32_t w,
+                                    const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t nreads,
+                                    uint64_t total_chars, uint8_t *d_digested, uint64_t digested_capacity,
+                                    uint64_t *d_out_offsets, uint16_t *d_out_lengths, uint64_t *d_out_pointers,
+                                    uint16_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                                    uint64_t max_value_thr, void *stream);
 
 /* ---- tuning knobs (optional) --------------------------------------------- */
-/* keys: "waves_per_cu" (occupancy target; default 20, 16 for alphabets of <= 16 letters), "lanes_per_wave" (reads per
+/* keys: "waves_per_cu" (occupancy target; default 16 for the plain PML walk, 12 with document ids / MS pointers, 20 for the
+ * state-machine walk), "digest_parked" (digest + query: 0 automatic, 1 always concatenate the digested reads, 2 leave them
+ * parked whenever the walk can take them), "lanes_per_wave" (reads per
  * wavefront, 0 = automatic; 1 = the one-wavefront-per-read mapping of SURVEY 7.1,
  * kept as a measurable experiment -- see DESIGN.md 4.1)                        */
 /* "minimizer_charhash": see the digestion section above                        */

@@ -42,6 +42,8 @@ EXPORTS = [
     "spx_digest_batch",
     "spx_digest_batch_device",
     "spx_digest_query_batch",
+    "spx_digest_query_batch_device",
+    "spx_digest_query_batch_device16",
     "spx_version",
     "spx_index_save",
     "spx_index_load_flat",
@@ -135,6 +137,8 @@ def lib() -> C.CDLL:
         L.spx_digest_batch.argtypes = [vp, i32, u32, u32, vp, vp, u64, vp, u64, vp]
         L.spx_digest_batch_device.argtypes = [vp, i32, u32, u32, vp, vp, u64, u64, vp, u64, vp, vp]
         L.spx_digest_query_batch.argtypes = [vp, i32, i32, u32, u32, vp, vp, u64, vp, u64, vp, vp, vp, vp, u64, u64]
+        for fn in (L.spx_digest_query_batch_device, L.spx_digest_query_batch_device16):
+            fn.argtypes = [vp, i32, i32, u32, u32, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp, u64, u64, vp]
         L.spx_version.restype = C.c_char_p
         L.spx_index_save.argtypes = [vp, C.c_char_p]
         L.spx_index_load_flat.restype = vp
@@ -379,6 +383,26 @@ class Index:
         _check(lib().spx_digest_batch_device(self._h, kind, k, w, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars,
                                              _t_ptr(d_out), cap, _t_ptr(d_out_offs), C.c_void_p(st.cuda_stream)))
         return d_out, d_out_offs
+
+    def digest_query_device(self, mode, kind, k, w, d_seqs, d_offs, total_chars, d_lengths=None, d_pointers=None, d_docs=None,
+                            d_class=None, bin_width=0, max_value_thr=0, stream=None, work=None):
+        """Digest and query in one call, everything on the device (spx_digest_query_batch_device[16]): returns
+        (d_out_offs, work).  The outputs (sized for total_chars entries) are laid out at d_out_offs; `work` = (digested
+        bytes, offsets) buffers that a caller may hand back to avoid the allocations."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        nreads = d_offs.numel() - 1
+        cap = int(lib().spx_digest_capacity(kind, k, total_chars))
+        if work is None or work[0].numel() < cap or work[1].numel() < nreads + 1:
+            work = (torch.empty(cap, dtype=torch.uint8, device=d_seqs.device),
+                    torch.empty(nreads + 1, dtype=torch.int64, device=d_seqs.device))
+        narrow = any(t is not None and t.element_size() == 2 for t in (d_lengths, d_docs))
+        fn = lib().spx_digest_query_batch_device16 if narrow else lib().spx_digest_query_batch_device
+        _check(fn(self._h, mode, kind, k, w, _t_ptr(d_seqs), _t_ptr(d_offs), nreads, total_chars, _t_ptr(work[0]), work[0].numel(),
+                  _t_ptr(work[1]), _t_ptr(d_lengths), _t_ptr(d_pointers), _t_ptr(d_docs), _t_ptr(d_class), bin_width, max_value_thr,
+                  C.c_void_p(st.cuda_stream)))
+        return work[1], work
 
     def digest_query_host(self, mode, kind, k, w, seqs, offs, want_lengths=True, want_docs=False, classify=None):
         """digest + query in one call (the reference's per-read loop body, for a batch)."""

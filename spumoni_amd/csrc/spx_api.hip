@@ -465,6 +465,10 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         ix->chunk_shift = (int)value;
         return SPX_OK;
     }
+    if (!strcmp(key, "digest_parked")) {  // 0 automatic, 1 never, 2 whenever the walk can (tests, A/B)
+        ix->digest_parked = (int)value;
+        return SPX_OK;
+    }
     if (!strcmp(key, "digest_kernel")) {
         ix->force_digest_kernel = (int)value;
         return SPX_OK;
@@ -504,6 +508,46 @@ int spx_digest_batch_device(spx_index* ix, int kind, uint32_t k, uint32_t w, con
     SPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     return launch_digest(ix, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_out_seqs, d_out_offsets, st);
+}
+
+// Digestion in front of a walk on the same device (run -m / -a, compute_ms_pml.cpp:919-923).  When the walk that follows
+// is the plain one over compact rows (k_walk_fast) and needs the reads only as characters, the digested reads stay where the
+// digestion parked them -- read q's at d_dig[d_offs[q] ..] -- and *in_starts = d_offs tells the walk so: the pass that would
+// concatenate them (0.5 of 2.1 ms per 10^7 x 200 bp) is not made.  d_dig_offs are the offsets of the concatenation either
+// way: that is where the results go.
+static int digest_for_walk(spx_index* ix, int mode, bool ms_lengths, int kind, uint32_t k, uint32_t w, const uint8_t* d_raw,
+                           const uint64_t* d_offs, uint64_t nreads, uint64_t total_in, uint8_t* d_dig, uint64_t cap,
+                           uint64_t* d_dig_offs, void* stream, const uint64_t** in_starts) {
+    *in_starts = nullptr;
+    if (!ix || !d_raw || !d_offs || !d_dig || !d_dig_offs) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    if (((uintptr_t)d_raw & 15) != 0) {
+        set_error("d_seqs must be 16-byte aligned (and readable for round_up(total_chars, 16) + 16 bytes)");
+        return SPX_E_ARG;
+    }
+    if (cap < spx_digest_capacity(kind, k, total_in)) {
+        set_error("the buffer for the digested reads must hold spx_digest_capacity() = %llu bytes",
+                  (unsigned long long)spx_digest_capacity(kind, k, total_in));
+        return SPX_E_ARG;
+    }
+    static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    if (ix->num_cus == 0) {
+        hipDeviceProp_t prop;
+        SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
+        ix->num_cus = prop.multiProcessorCount;
+    }
+    // (automatic: only batches that fill the device's lanes with reads -- the others may be long reads that the chunked
+    // walk should get, and that one takes its reads by their offsets)
+    bool park = ix->digest_parked != 1 && ix->rows != nullptr && ix->view.compact && !old_walk && nreads > 0 && nreads < (1ull << 31) &&
+                !(mode == SPX_MODE_MS && ms_lengths) && ix->force_lanes_per_wave == 0 &&
+                (ix->digest_parked == 2 || nreads * 2 > (uint64_t)ix->num_cus * 20 * 64);
+    const int rc = launch_digest(ix, kind, k, w, d_raw, d_offs, nreads, total_in, d_dig, d_dig_offs, (hipStream_t)stream, &park);
+    if (rc == SPX_OK && park) *in_starts = d_offs;
+    return rc;
 }
 
 // grow-only device scratch owned by the index (no hipMalloc/hipFree per call); callers hold host_mu
@@ -606,7 +650,8 @@ static int check_query(spx_index* ix, int mode, const void* seqs, const void* of
 static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, const uint64_t* d_offsets,
                              uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
                              uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
-                             uint64_t bin_width, uint64_t max_value_thr, void* stream, bool narrow) {
+                             uint64_t bin_width, uint64_t max_value_thr, void* stream, bool narrow,
+                             const uint64_t* d_in_starts = nullptr) {
     int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs,
                          d_out_class, bin_width);
     if (rc != SPX_OK) return rc;
@@ -639,11 +684,12 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     a.max_value_thr = max_value_thr;
     a.counters = ix->counters;
     a.narrow = narrow ? 1 : 0;
+    a.in_starts = d_in_starts;  // (reads parked by the digestion: digest_for_walk below made sure the plain fast walk takes them)
     if ((rc = prepare_len_mask(ix, mode, a)) != SPX_OK) return rc;
     SPX_HIP(hipEventRecord(ix->ev0, st));
     bool chunked = false, wrote = false;
     if (nreads > 0) {
-        if ((rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
+        if (!d_in_starts && (rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
         if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st, &wrote)) != SPX_OK) return rc;
     }
     SPX_HIP(hipEventRecord(ix->ev1, st));
@@ -682,7 +728,8 @@ int spx_query_batch_device16(spx_index* ix, int mode, const uint8_t* d_seqs, con
 // doc value in the host buffers (4, or 2 for the 16-bit entry points)
 static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const uint64_t* d_off, uint64_t nreads,
                          uint64_t total, void* out_lengths, uint64_t* out_pointers, void* out_docs,
-                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr, size_t width = 4) {
+                         spx_class* out_class, uint64_t bin_width, uint64_t max_value_thr, size_t width = 4,
+                         const uint64_t* d_in_starts = nullptr) {
     void *dlen = nullptr, *dptr = nullptr, *ddoc = nullptr, *dcls = nullptr;
     int rc;
     if (out_lengths && (rc = ensure_scratch(ix, 2, (total + 1) * 4, &dlen)) != SPX_OK) return rc;
@@ -690,7 +737,7 @@ static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const ui
     if (out_docs && (rc = ensure_scratch(ix, 4, (total + 1) * 4, &ddoc)) != SPX_OK) return rc;
     if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
     rc = query_device_impl(ix, mode, d_seq, d_off, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr,
-                           (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr, width == 2);
+                           (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr, width == 2, d_in_starts);
     if (rc != SPX_OK) return rc;
     SPX_HIP(hipDeviceSynchronize());
     if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen, total * width, hipMemcpyDeviceToHost));
@@ -951,8 +998,9 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
     SPX_HIP(hipMemcpy(draw, seqs, total, hipMemcpyHostToDevice));
     SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
-    rc = spx_digest_batch_device(ix, kind, k, w, (const uint8_t*)draw, (const uint64_t*)doff, nreads, total,
-                                 (uint8_t*)dseq, cap, (uint64_t*)dooff, nullptr);
+    const uint64_t* in_starts = nullptr;
+    rc = digest_for_walk(ix, mode, out_lengths != nullptr, kind, k, w, (const uint8_t*)draw, (const uint64_t*)doff, nreads, total,
+                         (uint8_t*)dseq, cap, (uint64_t*)dooff, nullptr, &in_starts);
     if (rc != SPX_OK) return rc;
     SPX_HIP(hipMemcpy(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost));  // synchronises
     const uint64_t dtotal = out_offsets[nreads];
@@ -963,7 +1011,44 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     }
     // the digested reads never leave the device: the walk starts from the scratch buffers
     return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)dooff, nreads, dtotal, out_lengths,
-                         out_pointers, out_docs, out_class, bin_width, max_value_thr);
+                         out_pointers, out_docs, out_class, bin_width, max_value_thr, 4, in_starts);
+}
+
+// The same with everything resident in HBM and asynchronous on `stream`: DNA reads in, results at the digested reads'
+// offsets (d_out_offsets) out.  What `run -m / -a` does to a read before matching_statistics (compute_ms_pml.cpp:919-923)
+// and the query itself, one call.
+static int digest_query_device_impl(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs,
+                                    const uint64_t* d_offsets, uint64_t nreads, uint64_t total_chars, uint8_t* d_digested,
+                                    uint64_t digested_capacity, uint64_t* d_out_offsets, uint32_t* d_out_lengths,
+                                    uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class, uint64_t bin_width,
+                                    uint64_t max_value_thr, void* stream, bool narrow) {
+    const uint64_t* in_starts = nullptr;
+    int rc = digest_for_walk(ix, mode, d_out_lengths != nullptr, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_digested,
+                             digested_capacity, d_out_offsets, stream, &in_starts);
+    if (rc != SPX_OK) return rc;
+    // (total_chars bounds the digested characters: it only sizes the walk's scratch)
+    return query_device_impl(ix, mode, d_digested, d_out_offsets, nreads, total_chars, d_out_lengths, d_out_pointers, d_out_docs,
+                             d_out_class, bin_width, max_value_thr, stream, narrow, in_starts);
+}
+
+int spx_digest_query_batch_device(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs,
+                                  const uint64_t* d_offsets, uint64_t nreads, uint64_t total_chars, uint8_t* d_digested,
+                                  uint64_t digested_capacity, uint64_t* d_out_offsets, uint32_t* d_out_lengths,
+                                  uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class, uint64_t bin_width,
+                                  uint64_t max_value_thr, void* stream) {
+    return digest_query_device_impl(ix, mode, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_digested, digested_capacity,
+                                    d_out_offsets, d_out_lengths, d_out_pointers, d_out_docs, d_out_class, bin_width, max_value_thr,
+                                    stream, false);
+}
+
+int spx_digest_query_batch_device16(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs,
+                                    const uint64_t* d_offsets, uint64_t nreads, uint64_t total_chars, uint8_t* d_digested,
+                                    uint64_t digested_capacity, uint64_t* d_out_offsets, uint16_t* d_out_lengths,
+                                    uint64_t* d_out_pointers, uint16_t* d_out_docs, spx_class* d_out_class, uint64_t bin_width,
+                                    uint64_t max_value_thr, void* stream) {
+    return digest_query_device_impl(ix, mode, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_digested, digested_capacity,
+                                    d_out_offsets, (uint32_t*)d_out_lengths, d_out_pointers, (uint32_t*)d_out_docs, d_out_class,
+                                    bin_width, max_value_thr, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1016,6 +1101,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     uint64_t total = total_in;
     bool narrow = true;
     for (uint64_t q = 0; q < nreads && narrow; ++q) narrow = offsets[q + 1] - offsets[q] < 65536;
+    const uint64_t* in_starts = nullptr;  // set when the digested reads stay where the digestion parked them
     if (digest_kind) {
         // perform_minimizer_digestion / perform_dna_minimizer_digestion (compute_ms_pml.cpp:919-923): the digested
         // reads never leave the device; the vectors are laid out at the digested offsets
@@ -1023,8 +1109,8 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         void *dd = nullptr, *ddo = nullptr;
         if ((rc = ensure_scratch(ix, 0, cap, &dd)) != SPX_OK) return rc;
         if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &ddo)) != SPX_OK) return rc;
-        rc = spx_digest_batch_device(ix, digest_kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total_in,
-                                     (uint8_t*)dd, cap, (uint64_t*)ddo, nullptr);
+        rc = digest_for_walk(ix, mode, want_len || out_class != nullptr, digest_kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff,
+                             nreads, total_in, (uint8_t*)dd, cap, (uint64_t*)ddo, nullptr, &in_starts);
         if (rc != SPX_OK) return rc;
         SPX_HIP(hipMemcpy(&total, (uint64_t*)ddo + nreads, 8, hipMemcpyDeviceToHost));  // synchronises
         wseq = (const uint8_t*)dd;
@@ -1037,7 +1123,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     if (want_doc && (rc = ensure_scratch(ix, 4, (total + 8) * 4, &ddoc)) != SPX_OK) return rc;
     if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
     rc = query_device_impl(ix, mode, wseq, woff, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr, (uint32_t*)ddoc,
-                           (spx_class*)dcls, bin_width, max_value_thr, nullptr, narrow);
+                           (spx_class*)dcls, bin_width, max_value_thr, nullptr, narrow, in_starts);
     if (rc != SPX_OK) return rc;
     lap("[digest +] walk");
     // count + scan per stream, then ONE read-back of the three sizes
@@ -1484,6 +1570,7 @@ spx_index* spx_index_clone(spx_index* src, int device) {
         ix->chunk_len = src->chunk_len;
         ix->force_lanes_per_wave = src->force_lanes_per_wave;
         ix->force_digest_kernel = src->force_digest_kernel;
+        ix->digest_parked = src->digest_parked;
         return rc;
     };
     if (body() != SPX_OK) {

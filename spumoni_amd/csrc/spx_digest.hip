@@ -23,6 +23,8 @@
 // concatenated with an offsets array, which is what the walk kernel takes.
 #include <hipcub/hipcub.hpp>
 
+#include <type_traits>
+
 #include "spx_internal.h"
 
 namespace spx {
@@ -39,6 +41,7 @@ struct DigestArgs {
     uint32_t wsz;   // k-mers per window
     uint32_t ring;  // power of two >= wsz + 64
     uint32_t xm;    // LEX_XOR_MASK restricted to the 2k bits of a k-mer
+    uint32_t tile;   // lane-per-read kernel: bytes of input staged in LDS at a time
     uint32_t tpack;  // -m: the four character hashes T[A] | T[C] << 8 | T[G] << 16 | T[T] << 24
     uint8_t key_of_kmer[256];  // sort key of every k-mer code: the hash (-m) or code ^ xm (-a)
     uint64_t* counts;          // pass 0: counts[q + 1] = bytes read q digests to
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(64) k_digest_wave(const DigestArgs a) {
 // sequentially, exactly like the reference's loop -- k-mer in a register, the window's keys in
 // one 64-bit register (newest in the low byte), minimum by packed 16-bit mins.  No ballots, no
 // stream compaction: a character outside ACGT just resets the lane's k-mer fill.
-constexpr uint32_t TILE = 16384;
+constexpr uint32_t TILE_MAX = 16384;  // the tile is a.tile bytes, a multiple of 1024: see launch_digest
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -176,10 +179,19 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int sft = 32; sft > 0; sft >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, sft));
+    return v;
+}
+
 template <int KIND, bool FAST8>
 __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
     constexpr int PASS = 2;  // count + park the minimizer bytes at the read's input offset (see below)
-    __shared__ uint4 tile16[TILE / 16 + 1];  // + slack for the last 4-byte read of a read
+    // the tile: a.tile bytes (dynamic shared memory: what 64 reads of the batch's mean length need, so that more
+    // wavefronts fit a CU -- 12.8 KB and 12 of them for 200 bp reads against 9 with the full 16 KB) + slack for the last
+    // 4-byte read of a read
+    extern __shared__ uint4 tile16[];
+    const uint32_t TILE = a.tile;
     __shared__ uint8_t lut[256];
     __shared__ uint32_t s_sel[16];  // v_perm selectors that pack the bytes named by a 4-bit mask (0x0c: a zero byte)
     const uint8_t* const tile = reinterpret_cast<const uint8_t*>(tile16);
@@ -234,8 +246,9 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
             constexpr uint32_t NB = 8;
             const uint32_t span = (uint32_t)(tend - t0);
             const uint8_t* const src = a.seqs + t0;
+            const uint32_t nch = TILE / 1024;  // chunks of 64 lanes x 16 bytes (a.tile is a multiple of 1024)
 #pragma unroll 1
-            for (uint32_t j0 = 0; j0 < TILE / 16 / 64; j0 += NB) {
+            for (uint32_t j0 = 0; j0 < nch; j0 += NB) {
                 // (named values, not an array: the array was left in scratch memory)
                 auto ld = [&](uint32_t j) {
                     const uint32_t o = ((j0 + j) * 64 + lane) * 16;
@@ -243,14 +256,15 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                 };
                 const uint4 v0 = ld(0), v1 = ld(1), v2 = ld(2), v3 = ld(3), v4 = ld(4), v5 = ld(5), v6 = ld(6), v7 = ld(7);
                 uint4* const dst = tile16 + j0 * 64 + lane;
+                const uint32_t left = nch - j0;  // (uniform)
                 dst[0 * 64] = v0;
-                dst[1 * 64] = v1;
-                dst[2 * 64] = v2;
-                dst[3 * 64] = v3;
-                dst[4 * 64] = v4;
-                dst[5 * 64] = v5;
-                dst[6 * 64] = v6;
-                dst[7 * 64] = v7;
+                if (left > 1) dst[1 * 64] = v1;
+                if (left > 2) dst[2 * 64] = v2;
+                if (left > 3) dst[3 * 64] = v3;
+                if (left > 4) dst[4 * 64] = v4;
+                if (left > 5) dst[5 * 64] = v5;
+                if (left > 6) dst[6 * 64] = v6;
+                if (left > 7) dst[7 * 64] = v7;
             }
             __syncthreads();
         };
@@ -276,7 +290,8 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                 // with its results masked away (vm) and its state put back afterwards
                 const uint32_t vm = nst ? 0xffffffffu : 0u;
                 const SwarState q_before = q;
-                auto step = [&](uint32_t st) {
+                auto step = [&](uint32_t st, auto masked_tag) {
+                    constexpr bool MASKED = decltype(masked_tag)::value;
                     uint32_t x;
                     __builtin_memcpy(&x, tile + off + 4 * st, 4);
                     const uint32_t pos = pos0 + 4 * st;
@@ -311,7 +326,7 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                     const uint32_t f = FE | (FO << 1);
                     uint32_t idx = (f | (f >> 14)) & 0xfu;
                     // positions that report: FIRST .. len - 1; the first report is always kept (:300 / :329)
-                    if (__builtin_amdgcn_ballot_w64(vm != 0 && (pos < FIRST + 2 || pos + 4 > len)) != 0) {  // (rare, and then for the whole wavefront)
+                    if (MASKED) {  // (the first three steps of a read and its last one)
                         const int32_t lo = (int32_t)FIRST - (int32_t)pos, hiq = (int32_t)len - (int32_t)pos;
                         const uint32_t l4 = lo < 0 ? 0u : (lo > 4 ? 4u : (uint32_t)lo), h4 = hiq < 0 ? 0u : (hiq > 4 ? 4u : (uint32_t)hiq);
                         const uint32_t pm = h4 > l4 ? ((1u << h4) - (1u << l4)) : 0u;
@@ -337,14 +352,30 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
                         e += 4;
                     }
                 };
-                // the steps every lane takes run without a predicate (reads of one length: all of them) ...
+                // the steps every lane takes run without a predicate (reads of one length: all of them), and those of them at
+                // which every lane is past its read's first reports and before its end without the position masks ...
                 uint32_t nst_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(nst ? nst : 0xffffffffu));
                 if (nst_all == 0xffffffffu) nst_all = 0;
-                for (uint32_t st = 0; st < nst_all; ++st) step(st);
+                const uint32_t f_l = pos0 >= FIRST + 2 ? 0u : (FIRST + 2 - pos0 + 3) >> 2;  // first step with pos >= FIRST + 2
+                const uint32_t e_l = len > pos0 ? (len - pos0) >> 2 : 0u;                    // steps with pos + 4 <= len
+                uint32_t st_f = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vm ? f_l : 0u));
+                uint32_t st_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(vm ? e_l : 0xffffffffu));
+                st_e = st_e < nst_all ? st_e : nst_all;
+                st_f = st_f < st_e ? st_f : st_e;
+                using Masked = std::integral_constant<bool, true>;
+                using Plain = std::integral_constant<bool, false>;
+                uint32_t st = 0;
+                for (; st < st_f; ++st) step(st, Masked{});
+                for (; st + 2 <= st_e; st += 2) {
+                    step(st, Plain{});
+                    step(st + 1, Plain{});
+                }
+                for (; st < st_e; ++st) step(st, Plain{});
+                for (; st < nst_all; ++st) step(st, Masked{});
                 if (!vm) q = q_before;
                 // ... the rest lane by lane
-                for (uint32_t st = nst_all; __builtin_amdgcn_ballot_w64(st < nst) != 0; ++st)
-                    if (st < nst) step(st);
+                for (st = nst_all; __builtin_amdgcn_ballot_w64(st < nst) != 0; ++st)
+                    if (st < nst) step(st, Masked{});
                 cur += take;
             }
             const uint32_t wt = KIND == SPX_DIGEST_PROMOTED ? promote4((uint32_t)acc) : (uint32_t)acc;
@@ -523,7 +554,12 @@ __global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* 
 }  // namespace
 
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
-                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st) {
+                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st, bool* parked) {
+    // *parked (in): the caller is the walk itself and can take the digested reads where the digestion parks them -- read
+    // q's bytes at d_out[d_offs[q] ..], d_out_offs its offsets in the concatenation that is then never made (no second
+    // pass over the bytes); (out): whether that is what happened (-m, lane-per-read kernel)
+    const bool want_parked = parked && *parked;
+    if (parked) *parked = false;
     if (kind != SPX_DIGEST_PROMOTED && kind != SPX_DIGEST_DNA) {
         set_error("digest kind must be SPX_DIGEST_PROMOTED (-m) or SPX_DIGEST_DNA (-a)");
         return SPX_E_ARG;
@@ -593,20 +629,33 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     if (lanes) {
         // one pass over the reads: minimizer bytes parked in a scratch buffer of the input's size,
         // moved to their place once the offsets are known
-        uint8_t* stash = nullptr;
-        SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
+        const bool park = want_parked && kind == SPX_DIGEST_PROMOTED;
+        uint8_t* stash = park ? d_out : nullptr;
+        if (!park) SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
         const uint64_t groups = (nreads + 63) / 64;
-        const uint32_t grid = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
+        // the tile: what 64 reads of mean length take (+ 3 %), in steps of 1 KB; a group that needs more goes through it in
+        // several (overlapping) tiles
+        uint64_t want = 64 * mean_len + 64 * mean_len / 32 + 64;
+        want = (want + 1023) / 1024 * 1024;
+        a.tile = (uint32_t)(want < 4096 ? 4096 : (want > TILE_MAX ? TILE_MAX : want));
+        const size_t lds_dyn = a.tile + 16;
+        const uint64_t per_cu = (160 * 1024) / (lds_dyn + 256 + 64 + 64);
+        const uint64_t waves = cus * (per_cu > 16 ? 16 : per_cu);
+        const uint32_t grid = (uint32_t)(groups < waves ? groups : waves);
         a.out = stash;
         if (kind == SPX_DIGEST_PROMOTED)
-            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_PROMOTED, true><<<grid, 64, 0, st>>>(a)
-                       : k_digest_lanes<SPX_DIGEST_PROMOTED, false><<<grid, 64, 0, st>>>(a);
+            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_PROMOTED, true><<<grid, 64, lds_dyn, st>>>(a)
+                       : k_digest_lanes<SPX_DIGEST_PROMOTED, false><<<grid, 64, lds_dyn, st>>>(a);
         else
-            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_DNA, true><<<grid, 64, 0, st>>>(a)
-                       : k_digest_lanes<SPX_DIGEST_DNA, false><<<grid, 64, 0, st>>>(a);
+            (a.wsz == 8 && k == 4) ? k_digest_lanes<SPX_DIGEST_DNA, true><<<grid, 64, lds_dyn, st>>>(a)
+                       : k_digest_lanes<SPX_DIGEST_DNA, false><<<grid, 64, lds_dyn, st>>>(a);
         SPX_HIP(hipGetLastError());
         int rc = scan_counts();
         if (rc != SPX_OK) return rc;
+        if (park) {
+            *parked = true;
+            return SPX_OK;
+        }
         a.out = d_out;
         const uint32_t grid2 = (uint32_t)(groups < cus * 16 ? groups : cus * 16);
         if (kind == SPX_DIGEST_PROMOTED)

@@ -113,6 +113,10 @@ struct BatchArgs {
     uint32_t narrow;          // out_lengths / out_docs point to uint16_t arrays (reads < 65536 characters)
     ChunkArgs ch;             // chunked walks only
     const uint32_t* only_flagged;  // plain walk: skip the reads whose flag is 0 (fallback after chunking)
+    // reads that were digested on the device a moment ago (spx_digest.hip) and are still where the digestion parked
+    // them: read q's characters are seqs[in_starts[q] ..), offs[q + 1] - offs[q] of them, while offs places its results
+    // as always (k_walk_fast only; null: seqs[offs[q] ..))
+    const uint64_t* in_starts;
     // PML, plain walk: the lengths leave the walk as ONE BIT per character (length == 0, i.e. "reset here":
     // a PML length is the distance to the next reset at or after it, compute_ms_pml.cpp:249-250, 266-276) and
     // k_expand_lengths writes out_lengths from the bits as a stream.  Read q's bits: 16-byte pairs of words
@@ -153,6 +157,7 @@ struct spx_index {
     int num_cus = 0;
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
     int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read
+    int digest_parked = 0;         // digest + walk: 0 the digested reads stay parked when the batch fills the device, 1 never, 2 whenever the walk can take them
     uint8_t charhash[4] = {0, 0, 0, 0};  // -m digestion: 8-bit character hashes of A, C, G, T
     char source_tag[128] = {0};          // spx_index_set_source_tag(): the caller's fingerprint of the index files
     // host-buffer queries of large batches run as a pipeline over chunks of reads: copy in,
@@ -253,5 +258,6 @@ int launch_text_write(const void* d_vals, int value_bytes, const uint64_t* d_off
 // spx_digest.hip: d_out_offs gets nreads + 1 offsets, d_out the digested reads (capacity is the
 // caller's business: spx_digest_capacity)
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
-                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t stream);
+                  uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t stream,
+                  bool* parked = nullptr);
 }  // namespace spx

@@ -1102,6 +1102,10 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
     constexpr int FCHUNK = CHUNK == 1 ? 1 : 0;  // k_walk_fast also walks pass 1 of the chunked walk; pass 2 is the state machine's
     const bool fast = COMPACT && CHUNK <= 1 && args.only_flagged == nullptr && !old_walk && items < (1ull << 31);
+    if (args.in_starts != nullptr && !(fast && CHUNK == 0)) {
+        set_error("internal: parked reads (BatchArgs::in_starts) are taken by the plain k_walk_fast only");
+        return SPX_E_ARG;
+    }
     // resident blocks per CU and CU count are looked up once per index and kernel variant
     const int slot = (fast ? 4 : 0) + MODE * 2 + (DOC ? 1 : 0);
     if (ix->occ_blocks[slot] == 0) {

@@ -416,6 +416,27 @@ int spx_digest_batch_device(spx_index *ix, int kind, uint32_t k, uint32_t w, con
     return no_device_memory();
 }
 
+int spx_digest_query_batch_device(spx_index *ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t *d_seqs,
+                                  const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars, uint8_t *d_digested,
+                                  uint64_t digested_capacity, uint64_t *d_out_offsets, uint32_t *d_out_lengths,
+                                  uint64_t *d_out_pointers, uint32_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                                  uint64_t max_value_thr, void *stream) {
+    (void)ix, (void)mode, (void)kind, (void)k, (void)w, (void)d_seqs, (void)d_offsets, (void)nreads, (void)total_chars;
+    (void)d_digested, (void)digested_capacity, (void)d_out_offsets, (void)d_out_lengths, (void)d_out_pointers;
+    (void)d_out_docs, (void)d_out_class, (void)bin_width, (void)max_value_thr, (void)stream;
+    return no_device_memory();
+}
+int spx_digest_query_batch_device16(spx_index *ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t *d_seqs,
+                                    const uint64_t *d_offsets, uint64_t nreads, uint64_t total_chars, uint8_t *d_digested,
+                                    uint64_t digested_capacity, uint64_t *d_out_offsets, uint16_t *d_out_lengths,
+                                    uint64_t *d_out_pointers, uint16_t *d_out_docs, spx_class *d_out_class, uint64_t bin_width,
+                                    uint64_t max_value_thr, void *stream) {
+    (void)ix, (void)mode, (void)kind, (void)k, (void)w, (void)d_seqs, (void)d_offsets, (void)nreads, (void)total_chars;
+    (void)d_digested, (void)digested_capacity, (void)d_out_offsets, (void)d_out_lengths, (void)d_out_pointers;
+    (void)d_out_docs, (void)d_out_class, (void)bin_width, (void)max_value_thr, (void)stream;
+    return no_device_memory();
+}
+
 /* digested reads + their offsets (malloc'ed) */
 static int digest_reads(spx_index *ix, int kind, uint32_t k, uint32_t w, const uint8_t *seqs, const uint64_t *offs,
                         uint64_t nreads, uint8_t **dseq, uint64_t **doff) {

@@ -136,6 +136,58 @@ def test_digest_then_query_equals_oracle_chain(gpu, oracle_mod, kind):
     assert np.array_equal(d_dseqs[:total].cpu().numpy(), dseqs)
 
 
+@pytest.mark.parametrize("kind", [capi.SPX_DIGEST_PROMOTED, capi.SPX_DIGEST_DNA])
+def test_digest_query_on_the_device_parked_and_concatenated(gpu, oracle_mod, kind):
+    """spx_digest_query_batch_device[16]: DNA reads resident on the device -> digestion -> walk in one call.  With
+    "digest_parked" = 2 the digested reads stay where the digestion parked them and the walk takes them by the reads' input
+    offsets (no concatenation pass; -m only), with 1 they are concatenated first: the same offsets, PML values, document ids,
+    classes, MS pointers -- the oracle's (compute_ms_pml.cpp:919-938, batch form).  Ragged reads, empty ones, reads shorter
+    than a window, characters outside ACGT."""
+    rng = np.random.default_rng(60 + kind)
+    genome = cases.repetitive_text(rng, 30000, DNA)
+    k, w = 4, 11
+    dtext = oracle_mod.digest(kind, k, w, genome)
+    raw = synth.index_from_text(torch.from_numpy(dtext.copy()), doc_lengths=[dtext.size // 2, dtext.size - dtext.size // 2])
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    ix = capi.Index.from_raw(raw, 0)
+    seqs, offs = cases.reads_mixed(rng, genome, DNA, 3000, 300, [ord("N")])
+    offs = offs.astype(np.uint64)
+    dseqs, doffs = oracle_mod.digest_batch(kind, k, w, seqs, offs)
+    want_l, want_d = orc.pml(dseqs, doffs.astype(np.int64), want_docs=True)
+    want_ms = orc.ms(dseqs, doffs.astype(np.int64), want_docs=True)
+    f, a, b, sm = oracle_mod.classify(want_l, doffs.astype(np.int64), 5, 2)
+    total_in = int(offs[-1])
+    d_seqs = torch.zeros(total_in + 64, dtype=torch.uint8, device="cuda")
+    d_seqs[:total_in] = torch.from_numpy(seqs).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    nreads = offs.size - 1
+    for parked in (2, 1, 0):
+        ix.set_option("digest_parked", parked)
+        for vt in (torch.int16, torch.int32):
+            d_len = torch.full((total_in + 8,), -1, dtype=vt, device="cuda")
+            d_doc = torch.full((total_in + 8,), -1, dtype=vt, device="cuda")
+            d_cls = torch.zeros((nreads, 2), dtype=torch.int64, device="cuda")
+            d_oo, _ = ix.digest_query_device(capi.SPX_MODE_PML, kind, k, w, d_seqs, d_offs, total_in, d_lengths=d_len, d_docs=d_doc,
+                                             d_class=d_cls, bin_width=5, max_value_thr=2)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_oo.cpu().numpy().astype(np.uint64), doffs), (parked, vt)
+            tot = int(doffs[-1])
+            mask = 0xffff if vt == torch.int16 else 0xffffffff
+            assert np.array_equal(d_len[:tot].cpu().numpy().astype(np.int64) & mask, want_l.astype(np.int64)), (parked, vt)
+            assert np.array_equal(d_doc[:tot].cpu().numpy().astype(np.int64) & mask, want_d.astype(np.int64)), (parked, vt)
+            cls = d_cls.cpu().numpy().view(capi.CLASS_DTYPE).reshape(-1)
+            assert np.array_equal(cls["above"], a) and np.array_equal(cls["sum_max"], sm), (parked, vt)
+        # MS pointers + document ids without lengths: the walk alone, so the parked reads serve it too
+        d_ptr = torch.zeros(total_in + 8, dtype=torch.int64, device="cuda")
+        d_doc = torch.zeros(total_in + 8, dtype=torch.int32, device="cuda")
+        ix.digest_query_device(capi.SPX_MODE_MS, kind, k, w, d_seqs, d_offs, total_in, d_pointers=d_ptr, d_docs=d_doc)
+        torch.cuda.synchronize()
+        tot = int(doffs[-1])
+        assert np.array_equal(d_ptr[:tot].cpu().numpy().view(np.uint64), want_ms["pointers"]), parked
+        assert np.array_equal(d_doc[:tot].cpu().numpy().view(np.uint32), want_ms["docs"]), parked
+    ix.set_option("digest_parked", 0)
+
+
 def test_digest_large_batch_properties(gpu, oracle_mod, small_index):
     """2*10^6 reads x 200 bp: sizes the oracle does not visit -- sampled reads against the oracle,
     plus size-independent properties (idempotent offsets, alphabet, density)."""
