@@ -259,6 +259,9 @@ def main(argv=None):
                     help="index the promoted-minimizer digestion of every sequence (files named <prefix>.bin*)")
     ap.add_argument("-a", "--dna-minimizer", action="store_true",
                     help="index the DNA-letter minimizer digestion of every sequence")
+    ap.add_argument("--serialized", action="store_true",
+                    help="also write <prefix>.thrbv.spumoni and <prefix>.thrbv.ms, the serialised indexes `spumoni run` loads "
+                         "(compute_ms_pml.cpp:192-213, 517-542; stream layout unverified against upstream, Python loops: small inputs)")
     ap.add_argument("-K", "--small-window", type=int, default=4)
     ap.add_argument("-W", "--large-window", type=int, default=11)
     a = ap.parse_args(argv)
@@ -320,6 +323,12 @@ def main(argv=None):
     with open(prefix + ".fdi", "w") as f:
         for i, ln in enumerate(doc_lengths):
             f.write(f"group_{i + 1}\t{ln}\n")
+    if a.serialized:
+        from spumoni_amd.sdsl_streams import write_thrbv
+
+        heads = np.maximum(raw.heads.numpy(), 1)
+        write_thrbv(prefix + ".thrbv.spumoni", heads, raw.lens.numpy(), raw.thr.numpy())
+        write_thrbv(prefix + ".thrbv.ms", heads, raw.lens.numpy(), raw.thr.numpy(), raw.ssa.numpy(), raw.esa.numpy())
     if a.doc:
         write_doc_array(prefix + ".doc", raw.doc_start.tolist(), raw.doc_end.tolist(), len(doc_lengths))
     # empirical null (compute_ms_pml.cpp:1409-1506): the null reads upper-cased, reversed, digested like the text;

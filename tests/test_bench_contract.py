@@ -61,7 +61,7 @@ def test_only_the_cpu_baseline_touches_the_oracle():
                 where.append(fn.name)
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
     assert not any("oracle" in ast.dump(n) for n in top)
-    assert set(where) <= {"cpu_baseline", "run_c4_ms_doc", "run_real_bwt", "run_real_bwt_ms_doc"}, where  # the legs' parity gates and the baseline
+    assert set(where) <= {"cpu_baseline", "run_c4_ms_doc", "run_real_bwt", "run_real_bwt_ms_doc", "run_long_reads_c5"}, where  # the legs' parity gates and the baseline
     assert "cpu_baseline" in where
 
 
