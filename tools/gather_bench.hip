@@ -51,6 +51,52 @@ __global__ void __launch_bounds__(256) k_chase(const uint4* __restrict__ tab, ui
     if (acc == 0x1234567) sink[0] = acc;
 }
 
+// 32-byte rows fetched by lane PAIRS: in each of the two load instructions lanes 2j and 2j + 1 take the two halves of ONE
+// row (row of lane 2j, then row of lane 2j + 1), so that an instruction touches 32 distinct lines instead of 64; the halves
+// go to their owners by DPP (quad_perm [1,0,3,2]).  Same bytes, same lines, half the per-instruction line lookups.
+__device__ __forceinline__ uint32_t swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
+__global__ void __launch_bounds__(256) k_chase_paired(const uint4* __restrict__ tab, uint64_t nrows, int iters, uint64_t* sink) {
+    uint64_t idx = mix(blockIdx.x * 256ull + threadIdx.x + 1) % nrows;
+    uint64_t acc = 0;
+    const bool odd = threadIdx.x & 1;
+    for (int i = 0; i < iters; ++i) {
+        const uint64_t pidx = ((uint64_t)swap1((uint32_t)(idx >> 32)) << 32) | swap1((uint32_t)idx);  // the partner's row
+        const uint64_t ra = odd ? pidx : idx, rb = odd ? idx : pidx;  // rows of the even lane, of the odd lane
+        const uint4 a = tab[ra * 2 + (odd ? 1 : 0)];  // instruction 1: the even lane's row, its two halves side by side
+        const uint4 b = tab[rb * 2 + (odd ? 1 : 0)];  // instruction 2: the odd lane's row
+        // even lane: own half 0 = a, own half 1 = partner's a; odd lane: own half 0 = partner's b, own half 1 = b
+        const uint32_t sax = swap1(a.x), say = swap1(a.y), saz = swap1(a.z), sbx = swap1(b.x), sby = swap1(b.y);
+        const uint32_t h0x = odd ? sbx : a.x, h0y = odd ? sby : a.y, h1z = odd ? b.z : saz;
+        (void)sax;
+        (void)say;
+        uint64_t h = h0x ^ ((uint64_t)h0y << 32);
+        h ^= h1z;
+        acc += h;
+        idx = mix(h + idx + i) % nrows;
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
+
+void run_paired(const uint4* tab, uint64_t bytes, uint64_t* sink, int blocks_per_cu, int ncu) {
+    const uint64_t nrows = bytes / 32;
+    const int iters = 2000;
+    const int grid = blocks_per_cu * ncu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    k_chase_paired<<<grid, 256>>>(tab, nrows, 100, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    k_chase_paired<<<grid, 256>>>(tab, nrows, iters, sink);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double loads = (double)grid * 256 * iters;
+    printf("B= 32 PAIRED lanes, blocks/CU=%d (waves/CU=%2d): %8.2f Grows/s  latency/iter %.0f ns\n", blocks_per_cu, blocks_per_cu * 4,
+           loads / ms / 1e6, ms * 1e6 / iters);
+}
+
 // calibration: two 16-byte gathers per iteration, either in the two 64-byte halves of
 // ONE random 128-byte-aligned line (SAME=1) or in two different random lines (SAME=0).
 // If the L2 fills whole 128-byte lines, SAME=1 costs one miss per iteration.
@@ -145,6 +191,7 @@ int main(int argc, char** argv) {
     for (int bpc : {1, 2, 4, 8}) {
         run<16>(tab, bytes, sink, bpc, ncu);
         run<32>(tab, bytes, sink, bpc, ncu);
+        run_paired(tab, bytes, sink, bpc, ncu);
         run<64>(tab, bytes, sink, bpc, ncu);
     }
     return 0;
