@@ -1468,7 +1468,8 @@ spx_index* spx_index_load_flat(const char* path, int device) {
         want[A_LETTERS] = 256 * sizeof(spx::LetterInfo);
         want[A_TEXT] = h.n_text ? h.n_text + 16 : 0;
         bool ok = r > 0 && r < 0xfffffff0ull && h.r > 0 && h.r <= r && h.n > 0 && h.view.n == h.n &&
-                  h.view.fat_stride == (aux ? 32u : 16u) && (h.n_text == 0 || h.n_text + 1 == h.n || h.n_text < h.n);
+                  (h.view.fat_stride == 32u || (!aux && h.view.fat_stride == 16u)) && (h.view.fat_stride == 16u || aux || h.view.compact) &&
+                  (h.n_text == 0 || h.n_text + 1 == h.n || h.n_text < h.n);
         for (int i = 0; ok && i < spx_index::NARR; ++i) {
             ok = h.arr_bytes[i] == want[i];
             const bool stored = i != A_FAT && i != A_FATJ && h.arr_bytes[i] != 0;

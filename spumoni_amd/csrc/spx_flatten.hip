@@ -283,7 +283,11 @@ __global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Au
             Hp = compact ? crow_H(pr) : row_H(pr);
         }
         *reinterpret_cast<FatRow*>(slot) = pack_fatrow(jr, j >= li.qend, j <= li.qbeg, force_esc != 0, single, Hp);
-        if (aux) *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
+        if (aux)
+            *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
+        else if (stride == 32)  // (PML-only, compact rows) the row of the landing run rides along: spx_walk_fast.inc, lrow
+            *reinterpret_cast<Row*>(slot + sizeof(FatRow)) =
+                srun <= r ? *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) + (uint64_t)srun * sizeof(Row32)) : Row{0, 0};
     }
 }
 
@@ -843,7 +847,11 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
     const bool has_ms = d_ssa && d_esa;
     const uint32_t fat_row_bytes = sizeof(FatRow);
-    const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs) ? (uint32_t)sizeof(Aux) : 0);
+    // SPX_FAT_LROW=1: a PML-only index with compact rows keeps the landing run's row in its fat slots (32-byte slots, half
+    // as many of them for the same budget; profiles/r04_fat_lrow.txt)
+    const bool want_lrow = getenv("SPX_FAT_LROW") != nullptr && atoi(getenv("SPX_FAT_LROW")) != 0;
+    const bool lrow = want_lrow && compact && !(has_ms || docs);
+    const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs || lrow) ? (uint32_t)sizeof(Aux) : 0);
     const double per_slot = fat_stride + 4 /* fat_j */;
     // per-run arrays: rows 16 / 32 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
     const double fixed = (double)r * ((double)row_bytes + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));

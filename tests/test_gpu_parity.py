@@ -448,3 +448,37 @@ def test_lane_and_occupancy_knobs_do_not_change_results(gpu, oracle_mod, lpw, wa
     ix.set_option("lanes_per_wave", lpw)
     ix.set_option("waves_per_cu", waves)
     _compare_all(oracle_mod, raw, text, seqs, offs, ix=ix)
+
+
+@pytest.mark.parametrize("slots", ["0.3", "2.0", "12"])
+def test_fat_slots_with_their_landing_row(gpu, oracle_mod, monkeypatch, slots):
+    """SPX_FAT_LROW=1 (experiment knob): a PML-only index with compact rows keeps, in the second half of a
+    32-byte fat slot, the row of the run the slot's jump lands in, and the step after such a jump goes on from it without
+    a landing gather.  The same values as the oracle's (compute_ms_pml.cpp:238-286) on a statistical index, on a real BWT
+    with bytes >= 128 and absent letters, through the chunked walk, and from the flat-layout cache."""
+    monkeypatch.setenv("SPX_FAT_LROW", "1")
+    monkeypatch.setenv("SPX_FAT_SLOTS_PER_RUN", slots)
+    raw = synth.statistical_rlbwt(40000, 60, 3.0, seed=11, zipf=1.0)
+    assert raw.ssa is None and raw.doc_start is None
+    seqs, offs = synth.simulate_reads(raw, 3000, 70, seed=5, positive_fraction=0.6, warmup=2)
+    seqs = seqs.cpu().numpy().copy()
+    seqs[::97] = 2  # a letter the index does not have
+    ix, st = _compare_all(oracle_mod, raw, None, seqs, offs.cpu().numpy())
+    d = ix.describe()
+    assert d["fat_stride"] == 32 and d["has_samples"] == 0 and d["compact_rows"] == 1
+    # long reads through the chunked walk (pass 1 is k_walk_fast too)
+    ls, lo = synth.simulate_reads(raw, 30, 1200, seed=6, positive_fraction=0.7, warmup=2)
+    ix.set_option("chunk_mode", 2)
+    got = ix.query_host(capi.SPX_MODE_PML, ls.cpu().numpy(), lo.cpu().numpy(), classify=(150, 5))
+    assert ix.last_chunk_stats()["chunk_len"] > 0
+    assert np.array_equal(got["lengths"], oracle_mod.OracleIndex.from_raw(raw.cpu()).pml(ls.cpu().numpy(), lo.cpu().numpy()))
+    ix.close()
+    # a real BWT with bytes >= 128 (the stay-put jump) and reads with absent letters; samples / documents dropped
+    from tests import cases
+
+    raw2, _ = cases.real_case(3, 5000, [3, 4, 5, 90, 127, 128, 129, 200, 255])
+    raw2.ssa = raw2.esa = raw2.doc_start = raw2.doc_end = None
+    rng = np.random.default_rng(8)
+    s2, o2 = cases.reads_mixed(rng, None, [3, 4, 5, 90, 127, 128, 129, 200, 255], 400, 120, [2, 250])
+    ix2, _ = _compare_all(oracle_mod, raw2, None, s2, o2)
+    assert ix2.describe()["fat_stride"] == 32
