@@ -44,6 +44,10 @@ def test_two_ranks_weak_counts_are_the_sum_of_the_single_runs():
     assert len(pr["ranks"]) == 2 and [r["reads"] for r in pr["ranks"]] == [200000, 200000]
     assert 0 < pr["min"] <= pr["max"]
     assert two["value"] > 0 and two["roofline"]["frac"] > 0
+    # ... and the line carries the OTHER scaling too: one set of 200 000 reads cut in two, same protocol
+    o = two["other_scaling"]
+    assert o["scaling"] == "strong" and o["reads_per_step"] == 200000 and o["classified_reads"] == 200000
+    assert sum(r["reads"] for r in o["per_rank_ms_per_step"]) == 200000 and o["value"] > 0
 
 
 @pytest.mark.gpu
@@ -55,6 +59,9 @@ def test_two_ranks_strong_cut_one_read_set():
     assert two["config"]["classified"] == one["config"]["classified"]  # the same 200 000 reads, cut in two
     assert two["config"]["classified"]["reads"] == 200000
     assert sum(r["reads"] for r in two["per_rank_ms_per_step"]["ranks"]) == 200000
+    o = two["other_scaling"]  # a strong line carries the weak figure beside it
+    assert o["scaling"] == "weak" and o["reads_per_step"] == 400000 and o["classified_reads"] == 400000
+    assert "other_scaling" not in one  # (one rank: the two are the same job)
     # the weak line of one rank walks the same reads (seed 13): same counts again
     assert _bench(["--gpus", "1"])["config"]["classified"] == one["config"]["classified"]
 
