@@ -45,7 +45,7 @@
 // Names the flat layout AND the walk kernels that read it: a .spx cache written by another layout is
 // refused, and measured HBM traffic (profiles/traffic.json) is only quoted for the version it was
 // taken with.  Bump on any change to a record in this file or to the walk's access pattern.
-#define SPX_LAYOUT_VERSION "spx-flat-r03c"
+#define SPX_LAYOUT_VERSION "spx-flat-r04a"
 
 namespace spx {
 
