@@ -44,6 +44,7 @@ struct DigestArgs {
     uint32_t tile;   // lane-per-read kernel: bytes of input staged in LDS at a time
     uint32_t tpack;  // -m: the four character hashes T[A] | T[C] << 8 | T[G] << 16 | T[T] << 24
     uint8_t key_of_kmer[256];  // sort key of every k-mer code: the hash (-m) or code ^ xm (-a)
+    const uint32_t* only;      // k_digest_wave: digest only the reads whose flag is set (null: all of them)
     uint64_t* counts;          // pass 0: counts[q + 1] = bytes read q digests to
     const uint64_t* out_offs;  // pass 1
     uint8_t* out;
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(64) k_digest_wave(const DigestArgs a) {
     const uint32_t k = a.k, wsz = a.wsz;
     const uint64_t lt = (1ull << lane) - 1;
     for (uint64_t rd = blockIdx.x; rd < a.nreads; rd += gridDim.x) {
+        if (a.only != nullptr && a.only[rd] == 0) continue;
         const uint64_t base = a.offs[rd];
         const uint64_t len = a.offs[rd + 1] - base;
         uint64_t ob = 0;
@@ -463,6 +465,189 @@ __global__ void __launch_bounds__(64) k_digest_lanes(const DigestArgs a) {
     }
 }
 
+// ---- long reads: lane per CHUNK --------------------------------------------------------------------------------------
+// A read of thousands of characters keeps one lane of the kernel above busy and sixty-three waiting, and the
+// wavefront-per-read kernel pays ballots and LDS rings for every 64 characters (120 G characters/s against 1 300 for short
+// reads).  But the packed walk depends on its past for eleven characters only: a k-mer on the three before it, a window on the
+// seven k-mers before that, an emit on the minimum one position back.  So an all-ACGT read is cut into chunks of CHUNK
+// characters, a LANE takes a chunk, starts HALO = 12 characters early with its emits masked, and produces exactly what the
+// sequential loop produces for the chunk's positions.  The chunks of a batch are consecutive in the input (a read's chunks,
+// then the next read's), so 64 of them are one stretch of at most 64 * 240 + 12 bytes: one tile.  Every chunk's bytes are
+// parked at the chunk's input offset and counted; ONE scan over the chunks gives every chunk's place in the concatenated
+// output -- a read's offset is its first chunk's -- and k_digest_unstash moves the pieces with the chunks in the role of the
+// reads.  A read with a character outside ACGT is flagged and redone by the wavefront-per-read kernel afterwards.
+constexpr uint32_t DCHUNK = 240, DHALO = 12;
+
+__global__ void k_dchunk_count(const uint64_t* offs, uint64_t nreads, uint64_t* cnt, uint32_t* bad) {
+    const uint64_t q = blockIdx.x * 256ull + threadIdx.x;
+    if (q > nreads) return;
+    cnt[q] = q < nreads ? (offs[q + 1] - offs[q] + DCHUNK - 1) / DCHUNK : 0;  // (exclusive scan: cnt[nreads] = chunks in all)
+    if (q < nreads) bad[q] = 0;
+}
+
+// chunk g: input offset c_start[g], read c_rd[g]; entries from the batch's last chunk up to `bound` are empty chunks at the
+// input's end (the launches are sized by the bound: nothing returns to the host)
+__global__ void k_dchunk_fill(const uint64_t* offs, uint64_t nreads, const uint64_t* first_chunk, uint64_t bound, uint64_t* c_start,
+                              uint32_t* c_rd) {
+    const uint64_t q = blockIdx.x * 256ull + threadIdx.x;
+    if (q < nreads) {
+        const uint64_t b = offs[q], e = offs[q + 1];
+        uint64_t g = first_chunk[q];
+        for (uint64_t at = b; at < e; at += DCHUNK, ++g) {
+            c_start[g] = at;
+            c_rd[g] = (uint32_t)q;
+        }
+    }
+    // (the entries between the count and the bound: every thread takes its share)
+    for (uint64_t g = first_chunk[nreads] + q; g <= bound; g += (uint64_t)gridDim.x * 256) {
+        c_start[g] = offs[nreads];
+        c_rd[g] = 0xffffffffu;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64) k_digest_chunks(const DigestArgs a, const uint64_t* c_start, const uint32_t* c_rd, uint64_t bound,
+                                                      uint64_t* c_count, uint32_t* bad) {
+    // (+ slack: a lane whose chunk is shorter than its neighbours' goes through their steps on whatever follows its own bytes)
+    __shared__ uint4 tile16[(64 * DCHUNK + 64 + 4 * DCHUNK) / 16 + 2];
+    __shared__ uint32_t s_sel[16];
+    const uint8_t* const tile = reinterpret_cast<const uint8_t*>(tile16);
+    const uint32_t lane = threadIdx.x;
+    if (lane < 16) {
+        uint32_t sel = 0x0c0c0c0cu, n = 0;
+        for (uint32_t j = 0; j < 4; ++j)
+            if ((lane >> j) & 1) {
+                sel = (sel & ~(0xffu << (8 * n))) | (j << (8 * n));
+                n++;
+            }
+        s_sel[lane] = sel;
+    }
+    auto rot4 = [](uint32_t v, uint32_t r) {
+        return r ? (((v << r) & (0x01010101u * ((0xffu << r) & 0xffu))) | ((v >> (8 - r)) & (0x01010101u * (0xffu >> (8 - r))))) : v;
+    };
+    const uint32_t T0 = a.tpack, R1 = rot4(a.tpack, 1), R2 = rot4(a.tpack, 2), R3 = rot4(a.tpack, 3);
+    const uint32_t xm4 = (a.xm & 0xffu) * 0x01010101u;
+    constexpr uint32_t FIRST = 10;
+    const uint64_t ngroups = (bound + 63) / 64;
+    for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint64_t g = grp * 64 + lane;
+        const bool in = g < bound;
+        const uint32_t rd = in ? c_rd[g] : 0xffffffffu;
+        const bool live = rd != 0xffffffffu;
+        const uint64_t cbeg = c_start[in ? g : bound];
+        const uint64_t rbeg = live ? a.offs[rd] : cbeg, rend = live ? a.offs[rd + 1] : cbeg;
+        const uint32_t pos0 = (uint32_t)(cbeg - rbeg);                                     // the chunk's first position in its read
+        const uint32_t len = live ? (uint32_t)min<uint64_t>(rend - cbeg, DCHUNK) : 0u;     // its positions
+        const uint32_t halo = pos0 ? DHALO : 0u;
+        // the tile: from the first chunk's halo to the last chunk's end (dead lanes sit at the input's end)
+        const uint64_t lo_all = __shfl(cbeg - halo, 0), hi_all = __shfl(cbeg + len, 63);
+        const uint64_t t0 = lo_all & ~15ull, tend = (hi_all + 15) & ~15ull;
+        __syncthreads();
+        for (uint64_t o = (uint64_t)lane * 16; t0 + o < tend; o += 64 * 16) tile16[o >> 4] = *reinterpret_cast<const uint4*>(a.seqs + t0 + o);
+        __syncthreads();
+        const uint32_t off = (uint32_t)(cbeg - halo - t0);
+        const uint32_t nst = (halo + len + 3) >> 2;
+        const uint32_t end = pos0 + len;
+        const uint32_t first_ok = pos0 > FIRST ? pos0 : FIRST;  // the chunk's first position that may emit
+        const uint32_t full = (halo + len) >> 2;  // steps with four positions of the chunk (or its halo)
+        SwarState q{0, 0, 0, 0, 0, 0, 0};
+        uint64_t acc = 0, e = 0;
+        uint32_t nacc = 0, wrong = 0;
+        auto step = [&](uint32_t st, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            uint32_t x;
+            __builtin_memcpy(&x, tile + off + 4 * st, 4);
+            const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+            const uint32_t inval = __builtin_amdgcn_perm(0x54474341u, 0x54474341u, t) ^ x;
+            const uint32_t t1 = __builtin_amdgcn_alignbyte(t, q.tp, 3), t2 = __builtin_amdgcn_alignbyte(t, q.tp, 2),
+                           t3 = __builtin_amdgcn_alignbyte(t, q.tp, 1);
+            q.tp = t;
+            uint32_t key;
+            if (KIND == SPX_DIGEST_PROMOTED)
+                key = __builtin_amdgcn_perm(T0, T0, t) ^ __builtin_amdgcn_perm(R1, R1, t1) ^ __builtin_amdgcn_perm(R2, R2, t2) ^
+                      __builtin_amdgcn_perm(R3, R3, t3);
+            else
+                key = (t | (t1 << 2) | (t2 << 4) | (t3 << 6)) ^ xm4;
+            const uint32_t E = key & 0x00ff00ffu, O = (key >> 8) & 0x00ff00ffu;
+            const uint32_t AE = pk_min_u16(E, __builtin_amdgcn_alignbit(O, q.Op, 16)), AO = pk_min_u16(O, E);
+            const uint32_t BE = pk_min_u16(AE, __builtin_amdgcn_alignbit(AE, q.AEp, 16)),
+                           BO = pk_min_u16(AO, __builtin_amdgcn_alignbit(AO, q.AOp, 16));
+            const uint32_t CE = pk_min_u16(BE, q.BEp), CO = pk_min_u16(BO, q.BOp);
+            const uint32_t XE = CE ^ __builtin_amdgcn_alignbit(CO, q.COp, 16), XO = CO ^ CE;
+            q.Op = O;
+            q.AEp = AE;
+            q.AOp = AO;
+            q.BEp = BE;
+            q.BOp = BO;
+            q.COp = CO;
+            const uint32_t FE = ((XE + 0x00ff00ffu) >> 8) & 0x00010001u, FO = ((XO + 0x00ff00ffu) >> 8) & 0x00010001u;
+            const uint32_t f = FE | (FO << 1);
+            uint32_t idx = (f | (f >> 14)) & 0xfu;
+            if (MASKED) {  // the halo (or a read's first ten positions) and the chunk's last step
+                const int32_t pos = (int32_t)(pos0 - halo + 4 * st);
+                const int32_t lo = (int32_t)first_ok - pos, hiq = (int32_t)end - pos, own = (int32_t)pos0 - pos;
+                const uint32_t l4 = lo < 0 ? 0u : (lo > 4 ? 4u : (uint32_t)lo), h4 = hiq < 0 ? 0u : (hiq > 4 ? 4u : (uint32_t)hiq);
+                const uint32_t o4 = own < 0 ? 0u : (own > 4 ? 4u : (uint32_t)own);  // bytes of the step that are the chunk before's
+                const uint32_t pm = h4 > l4 ? ((1u << h4) - (1u << l4)) : 0u;
+                const int32_t fo = (int32_t)FIRST - pos;  // a read's first report is always kept (:300 / :329)
+                idx = (idx & pm) | ((pos0 == 0 && fo >= 0 && fo < 4 && (uint32_t)fo < h4) ? (1u << fo) : 0u);
+                const uint32_t keep = (h4 >= 4 ? 0xffffffffu : ((1u << (8 * h4)) - 1u)) & (o4 >= 4 ? 0u : ~((1u << (8 * o4)) - 1u));
+                wrong |= inval & keep;
+            } else {  // (a lane that is past its chunk's end goes along with nothing kept)
+                const uint32_t lm = st < full ? 0xffffffffu : 0u;
+                wrong |= inval & lm;
+                idx &= lm;
+            }
+            const uint32_t vals = CE | (CO << 8);
+            const uint32_t comp = __builtin_amdgcn_perm(vals, vals, s_sel[idx]);
+            acc |= (uint64_t)comp << (8 * nacc);
+            nacc += (uint32_t)__popc(idx);
+            if (nacc >= 4) {
+                const uint32_t w4 = KIND == SPX_DIGEST_PROMOTED ? promote4((uint32_t)acc) : (uint32_t)acc;
+                __builtin_memcpy(a.out + cbeg + e, &w4, 4);
+                acc >>= 32;
+                nacc -= 4;
+                e += 4;
+            }
+        };
+        using Masked = std::integral_constant<bool, true>;
+        using Plain = std::integral_constant<bool, false>;
+        // Steps 0 .. 2 are the halo (or a read's first positions): masked.  From there on every lane takes every step of the
+        // wavefront's longest chunk, plain ones -- but the step at which some lane's chunk ends inside the four characters, which
+        // is a masked step for the whole wavefront (a chunk that has ended keeps nothing in either kind of step).
+        const uint32_t nst_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nst));
+        uint32_t st = 0;
+        for (; st < 3 && st < nst_max; ++st) step(st, Masked{});
+        for (; st < nst_max; ++st) {
+            if (__builtin_amdgcn_ballot_w64(st >= full && st < nst) != 0)
+                step(st, Masked{});
+            else
+                step(st, Plain{});
+        }
+        const uint32_t wt = KIND == SPX_DIGEST_PROMOTED ? promote4((uint32_t)acc) : (uint32_t)acc;
+        for (uint32_t j = 0; j < nacc; ++j) a.out[cbeg + e + j] = (uint8_t)(wt >> (8 * j));
+        e += nacc;
+        if (in) c_count[g + 1] = live ? e * (KIND == SPX_DIGEST_DNA ? a.k : 1) : 0;
+        if (live && wrong) atomicOr(&bad[rd], 1u);
+    }
+}
+
+// a flagged read (a character outside ACGT) is the wavefront-per-read kernel's: its bytes count in its first chunk
+__global__ void k_dchunk_fix_counts(const uint32_t* c_rd, const uint64_t* first_chunk, const uint32_t* bad, const uint64_t* read_count,
+                                    uint64_t bound, uint64_t* c_count) {
+    const uint64_t g = blockIdx.x * 256ull + threadIdx.x;
+    if (g >= bound) return;
+    const uint32_t rd = c_rd[g];
+    if (rd == 0xffffffffu || !bad[rd]) return;
+    c_count[g + 1] = first_chunk[rd] == g ? read_count[rd + 1] : 0;
+}
+
+// read q's offset in the concatenated output is its first chunk's
+__global__ void k_dchunk_read_offsets(const uint64_t* first_chunk, const uint64_t* c_out, uint64_t nreads, uint64_t* out_offs) {
+    const uint64_t q = blockIdx.x * 256ull + threadIdx.x;
+    if (q <= nreads) out_offs[q] = c_out[first_chunk[q]];
+}
+
 // Second half of the one-pass digestion: the minimizer bytes of read q wait at stash[offs[q] ..];
 // 64 consecutive reads go to one contiguous stretch of the output, so the wavefront assembles that
 // stretch in LDS (every lane fetches its read's bytes with 16-byte loads, -a spells the k-mers
@@ -573,6 +758,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         return SPX_E_ARG;
     }
     DigestArgs a;
+    a.only = nullptr;
     a.seqs = d_seqs;
     a.offs = d_offs;
     a.nreads = nreads;
@@ -613,7 +799,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     // short reads and a window that fits a register: one lane per read; otherwise one
     // wavefront per read (any length, any window)
     const uint64_t mean_len = total_chars / nreads;
-    bool lanes = a.wsz <= 8 && mean_len <= 2048;
+    bool lanes = a.wsz <= 8 && mean_len <= 2048;  // (k = 4, w = 11 above 640 characters: by chunks, below)
     if (ix->force_digest_kernel == 1) lanes = a.wsz <= 8;
     if (ix->force_digest_kernel == 2) lanes = false;
     const uint64_t cus = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256);
@@ -626,6 +812,84 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         SPX_HIP(hipFreeAsync(tmp, st));
         return SPX_OK;
     };
+    // long reads of the default shape: a lane per chunk of 240 characters (k_digest_chunks)
+    // (tools/digest_bench.py --kernel 1 / 3: the lane-per-read kernel wins up to ~500 characters -- 3.2 against 3.4 ms per
+    // 1.8e9 characters --, at 1 000 the chunks are 2 x faster, at 2 000 4.5 x: a group of 64 reads no longer fits a tile)
+    bool by_chunks = a.wsz == 8 && k == 4 && mean_len > 640;
+    if (ix->force_digest_kernel == 3) by_chunks = a.wsz == 8 && k == 4;
+    if (ix->force_digest_kernel == 1 || ix->force_digest_kernel == 2) by_chunks = false;
+    if (by_chunks) {
+        const uint64_t bound = total_chars / DCHUNK + nreads + 1;  // chunks: at most this many (the count stays on the device)
+        uint64_t *first_chunk = nullptr, *c_start = nullptr, *c_count = nullptr, *rcount = nullptr;
+        uint32_t *c_rd = nullptr, *bad = nullptr;
+        uint8_t* stash = nullptr;
+        SPX_HIP(hipMallocAsync((void**)&first_chunk, (nreads + 2) * 8, st));
+        SPX_HIP(hipMallocAsync((void**)&rcount, (nreads + 2) * 8, st));
+        SPX_HIP(hipMallocAsync((void**)&bad, (nreads + 1) * 4, st));
+        SPX_HIP(hipMallocAsync((void**)&c_start, (bound + 2) * 8, st));
+        SPX_HIP(hipMallocAsync((void**)&c_count, (bound + 2) * 8, st));
+        SPX_HIP(hipMallocAsync((void**)&c_rd, (bound + 2) * 4, st));
+        SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
+        auto scan = [&](uint64_t* v, uint64_t count, bool inclusive) -> int {
+            size_t tmp_bytes = 0;
+            void* tmp = nullptr;
+            if (inclusive)
+                SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, v, v, count, st));
+            else
+                SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, v, v, count, st));
+            SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+            if (inclusive)
+                SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, v, v, count, st));
+            else
+                SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, v, v, count, st));
+            SPX_HIP(hipFreeAsync(tmp, st));
+            return SPX_OK;
+        };
+        const unsigned gq = (unsigned)((nreads + 1 + 255) / 256), gc = (unsigned)((bound + 255) / 256);
+        k_dchunk_count<<<gq, 256, 0, st>>>(d_offs, nreads, first_chunk, bad);
+        int rc = scan(first_chunk, nreads + 1, false);
+        if (rc != SPX_OK) return rc;
+        k_dchunk_fill<<<gq, 256, 0, st>>>(d_offs, nreads, first_chunk, bound, c_start, c_rd);
+        SPX_HIP(hipMemsetAsync(c_count, 0, 8, st));
+        a.out = stash;
+        const uint64_t groups = (bound + 63) / 64;
+        const uint32_t gridc = (uint32_t)(groups < cus * 9 ? groups : cus * 9);
+        if (kind == SPX_DIGEST_PROMOTED)
+            k_digest_chunks<SPX_DIGEST_PROMOTED><<<gridc, 64, 0, st>>>(a, c_start, c_rd, bound, c_count, bad);
+        else
+            k_digest_chunks<SPX_DIGEST_DNA><<<gridc, 64, 0, st>>>(a, c_start, c_rd, bound, c_count, bad);
+        SPX_HIP(hipGetLastError());
+        // the reads with a character outside ACGT: counted by the wavefront-per-read kernel (it returns at once for the others)
+        const size_t lds = 2 * (size_t)ring + 256;
+        const uint32_t gridw = (uint32_t)(nreads < cus * 64 ? nreads : cus * 64);
+        DigestArgs aw = a;
+        aw.only = bad;
+        aw.counts = rcount;
+        k_digest_wave<0><<<gridw, 64, lds, st>>>(aw);
+        k_dchunk_fix_counts<<<gc, 256, 0, st>>>(c_rd, first_chunk, bad, rcount, bound, c_count);
+        rc = scan(c_count, bound + 1, true);  // c_count[g]: where chunk g's bytes go in the concatenated output
+        if (rc != SPX_OK) return rc;
+        k_dchunk_read_offsets<<<gq, 256, 0, st>>>(first_chunk, c_count, nreads, d_out_offs);
+        DigestArgs au = a;
+        au.offs = c_start;
+        au.out_offs = c_count;
+        au.nreads = bound;
+        au.out = d_out;
+        const uint32_t grid2 = (uint32_t)(groups < cus * 16 ? groups : cus * 16);
+        if (kind == SPX_DIGEST_PROMOTED)
+            k_digest_unstash<SPX_DIGEST_PROMOTED><<<grid2, 64, 0, st>>>(au, stash);
+        else
+            k_digest_unstash<SPX_DIGEST_DNA><<<grid2, 64, 0, st>>>(au, stash);
+        aw.out_offs = d_out_offs;
+        aw.out = d_out;
+        k_digest_wave<1><<<gridw, 64, lds, st>>>(aw);
+        SPX_HIP(hipGetLastError());
+        for (void* p : {(void*)first_chunk, (void*)rcount, (void*)bad, (void*)c_start, (void*)c_count, (void*)c_rd, (void*)stash})
+            SPX_HIP(hipFreeAsync(p, st));
+        k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
+        SPX_HIP(hipGetLastError());
+        return SPX_OK;
+    }
     if (lanes) {
         // one pass over the reads: minimizer bytes parked in a scratch buffer of the input's size,
         // moved to their place once the offsets are known

@@ -156,7 +156,7 @@ struct spx_index {
     int occ_blocks[8] = {};  // resident 256-thread blocks per CU, per kernel variant (4..7: k_walk_fast)
     int num_cus = 0;
     int force_lanes_per_wave = 0;  // experiment knob: 0 = automatic
-    int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read
+    int force_digest_kernel = 0;   // test knob: 0 automatic, 1 lane-per-read, 2 wavefront-per-read, 3 lane-per-chunk
     int digest_parked = 0;         // digest + walk: 0 the digested reads stay parked when the batch fills the device, 1 never, 2 whenever the walk can take them
     uint8_t charhash[4] = {0, 0, 0, 0};  // -m digestion: 8-bit character hashes of A, C, G, T
     char source_tag[128] = {0};          // spx_index_set_source_tag(): the caller's fingerprint of the index files

@@ -43,7 +43,7 @@ def test_digest_matches_oracle(gpu, oracle_mod, small_index, kind, k, w):
     for p_n, maxlen in ((0.0, 700), (0.05, 700), (0.01, 120)):
         seqs, offs = _ragged_dna(rng, 400, maxlen, p_n)
         want, want_offs = oracle_mod.digest_batch(kind, k, w, seqs, offs)
-        for forced in (0, 1, 2):  # automatic, lane-per-read (when the window allows), wavefront-per-read
+        for forced in (0, 1, 2, 3):  # automatic, lane-per-read (when the window allows), wavefront-per-read, lane-per-chunk (k = 4, w = 11)
             ix.set_option("digest_kernel", forced)
             got, got_offs = ix.digest_host(kind, k, w, seqs, offs)
             assert np.array_equal(got_offs, want_offs), forced
@@ -65,7 +65,7 @@ def test_digest_edge_batches(gpu, oracle_mod, small_index):
             offs = np.array([0, seqs.size], np.uint64)
         for kind in (1, 2):
             want, want_offs = oracle_mod.digest_batch(kind, 4, 11, seqs, offs)
-            for forced in (1, 2, 0):
+            for forced in (1, 2, 3, 0):
                 ix.set_option("digest_kernel", forced)
                 got, got_offs = ix.digest_host(kind, 4, 11, seqs, offs)
                 assert np.array_equal(got_offs, want_offs) and np.array_equal(got, want)
@@ -186,6 +186,34 @@ def test_digest_query_on_the_device_parked_and_concatenated(gpu, oracle_mod, kin
         assert np.array_equal(d_ptr[:tot].cpu().numpy().view(np.uint64), want_ms["pointers"]), parked
         assert np.array_equal(d_doc[:tot].cpu().numpy().view(np.uint32), want_ms["docs"]), parked
     ix.set_option("digest_parked", 0)
+
+
+@pytest.mark.parametrize("kind", [capi.SPX_DIGEST_PROMOTED, capi.SPX_DIGEST_DNA])
+def test_long_reads_are_digested_by_chunks(gpu, oracle_mod, small_index, kind):
+    """Reads of thousands of characters (BASELINE config 5 before digestion) take the lane-per-chunk kernel: every chunk of 240
+    characters a lane, started twelve characters early, its bytes parked, one scan, the pieces moved -- the same bytes and
+    offsets as the oracle's sequential loop (src/spumoni.cpp:294-342), also for reads whose length is a multiple of the chunk,
+    one character more or less, shorter than a window, empty, and for reads with characters outside ACGT (flagged, redone by
+    the wavefront-per-read kernel)."""
+    ix = small_index[2]
+    rng = np.random.default_rng(300 + kind)
+    lens = [9000, 240, 241, 239, 480, 0, 7, 11, 10, 12, 2400, 2399, 2401, 5000, 1, 252, 15000, 3333]
+    lens += rng.integers(2500, 12000, size=40).tolist()
+    reads = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=n)].copy() for n in lens]
+    for i in (3, 13, 20, 21, 35):  # characters outside ACGT: at a chunk boundary, in a halo, in the middle, at the end
+        if reads[i].size:
+            for at in (0, 239, 240, 251, reads[i].size // 2, reads[i].size - 1):
+                if at < reads[i].size:
+                    reads[i][at] = ord("N")
+    seqs = np.concatenate(reads)
+    offs = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.uint64)
+    want, want_offs = oracle_mod.digest_batch(kind, 4, 11, seqs, offs)
+    for forced in (0, 3, 2):
+        ix.set_option("digest_kernel", forced)
+        got, got_offs = ix.digest_host(kind, 4, 11, seqs, offs)
+        assert np.array_equal(got_offs, want_offs), forced
+        assert np.array_equal(got, want), forced
+    ix.set_option("digest_kernel", 0)
 
 
 def test_digest_large_batch_properties(gpu, oracle_mod, small_index):

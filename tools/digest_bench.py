@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--w", type=int, default=11)
     ap.add_argument("--cpu-reads", type=int, default=200_000)
+    ap.add_argument("--kernel", type=int, default=0, help="digest_kernel option: 0 automatic, 1 lane per read, 2 wavefront per read, 3 lane per chunk")
     a = ap.parse_args()
     ix = capi.digester(0)
+    ix.set_option("digest_kernel", a.kernel)
     g = torch.Generator(device="cuda").manual_seed(1)
     n = a.reads * a.len
     d_seqs = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[
