@@ -533,6 +533,9 @@ static int digest_for_walk(spx_index* ix, int mode, bool ms_lengths, int kind, u
         return SPX_E_ARG;
     }
     static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
+    // (SPX_DIGEST_PARKED: the "digest_parked" option from the environment, for callers that have no handle on it -- the CLI's tests)
+    static const int env_parked = getenv("SPX_DIGEST_PARKED") ? atoi(getenv("SPX_DIGEST_PARKED")) : -1;
+    const int parked_mode = env_parked >= 0 ? env_parked : ix->digest_parked;
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
     if (ix->num_cus == 0) {
@@ -542,9 +545,9 @@ static int digest_for_walk(spx_index* ix, int mode, bool ms_lengths, int kind, u
     }
     // (automatic: only batches that fill the device's lanes with reads -- the others may be long reads that the chunked
     // walk should get, and that one takes its reads by their offsets)
-    bool park = ix->digest_parked != 1 && ix->rows != nullptr && ix->view.compact && !old_walk && nreads > 0 && nreads < (1ull << 31) &&
+    bool park = parked_mode != 1 && ix->rows != nullptr && ix->view.compact && !old_walk && nreads > 0 && nreads < (1ull << 31) &&
                 !(mode == SPX_MODE_MS && ms_lengths) && ix->force_lanes_per_wave == 0 &&
-                (ix->digest_parked == 2 || nreads * 2 > (uint64_t)ix->num_cus * 20 * 64);
+                (parked_mode == 2 || nreads * 2 > (uint64_t)ix->num_cus * 20 * 64);
     const int rc = launch_digest(ix, kind, k, w, d_raw, d_offs, nreads, total_in, d_dig, d_dig_offs, (hipStream_t)stream, &park);
     if (rc == SPX_OK && park) *in_starts = d_offs;
     return rc;

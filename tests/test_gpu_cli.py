@@ -344,6 +344,20 @@ def test_cli_with_minimizer_digestion(built, tmp_path, oracle_mod, digest, kw):
         assert (b"promoted minimizer alphabet" if digest == "m" else b"DNA minimizer alphabet") in r.stderr
 
 
+def test_cli_walks_the_digested_reads_where_they_were_parked(built, tmp_path, oracle_mod, monkeypatch):
+    """`run -m` with SPX_DIGEST_PARKED=2: the device's text path (spx_query_text_begin) leaves the digested reads where the
+    digestion parked them and the walk takes them by the reads' input offsets -- what a super-batch of hundreds of thousands
+    of reads gets by itself.  Every file byte-identical to the oracle harness (compute_ms_pml.cpp:919-938), PML
+    with documents and report, and MS pointers (`-M` needs the lengths: concatenated, the same files)."""
+    monkeypatch.setenv("SPX_DIGEST_PARKED", "2")
+    ref, prefix, seqs, offs, rng = _setup_digested(tmp_path, oracle_mod, 1, 4, 11, seed=66)
+    for mode, flags in (("-P", ["-c", "-d", "-w", "50"]), ("-P", []), ("-M", ["-c", "-d", "-w", "50"])):
+        _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, flags, mode, digest="m")
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "4000")  # several super-batches, two workers
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0")
+    _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P", digest="m")
+
+
 def test_cli_read_empty_after_digestion_is_fatal_in_order(built, tmp_path, oracle_mod):
     """:926-931 -- a read that digests to nothing (all N / shorter than one window) stops the run
     at that read; what came before is on disk."""
