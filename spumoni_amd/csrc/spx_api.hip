@@ -153,6 +153,18 @@ static int init_runtime(spx_index* ix) {
     SPX_HIP(hipEventCreate(&ix->ev0));
     SPX_HIP(hipEventCreate(&ix->ev1));
     SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
+    {
+        // The stream-ordered scratch of the digestion (hipMallocAsync: the parked bytes, the scans' workspace) comes from the
+        // device's default pool, which by default hands freed memory back to the system at the next synchronisation -- and
+        // maps it again at the next call: tens of milliseconds for a 2 GB block, on and off (a 2 ms digestion was seen to take
+        // 37-71 ms in whole runs of tools/digest_bench.py).  The pool keeps what it has been given.
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, ix->device) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     SPX_HIP(hipDeviceSynchronize());
     return SPX_OK;
 }

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) k_digest_wave(const DigestArgs a) {
 // sequentially, exactly like the reference's loop -- k-mer in a register, the window's keys in
 // one 64-bit register (newest in the low byte), minimum by packed 16-bit mins.  No ballots, no
 // stream compaction: a character outside ACGT just resets the lane's k-mer fill.
-constexpr uint32_t TILE_MAX = 16384;  // the tile is a.tile bytes, a multiple of 1024: see launch_digest
+constexpr uint32_t TILE_MAX = 32768;  // the tile is a.tile bytes, a multiple of 1024: see launch_digest
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
