@@ -157,10 +157,10 @@ static int init_runtime(spx_index* ix) {
         // The stream-ordered scratch of the digestion (hipMallocAsync: the parked bytes, the scans' workspace) comes from the
         // device's default pool, which by default hands freed memory back to the system at the next synchronisation -- and
         // maps it again at the next call: tens of milliseconds for a 2 GB block, on and off (a 2 ms digestion was seen to take
-        // 37-71 ms in whole runs of tools/digest_bench.py).  The pool keeps what it has been given.
+        // 37-71 ms in whole runs of tools/digest_bench.py).  The pool keeps up to 4 GB of what it has been given.
         hipMemPool_t pool = nullptr;
         if (hipDeviceGetDefaultMemPool(&pool, ix->device) == hipSuccess && pool) {
-            uint64_t keep = ~0ull;
+            uint64_t keep = 4ull << 30;  // (up to 4 GB: a batch's scratch, not what a one-off giant call asked for)
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
         }
         (void)hipGetLastError();
