@@ -1428,7 +1428,13 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
         SPX_HIP(hipGetDeviceProperties(&prop, ix->device));
         ix->num_cus = prop.multiProcessorCount;
     }
-    const uint64_t lanes = (uint64_t)ix->num_cus * 20 * 64;  // what the walk keeps resident
+    // what the walk keeps resident: launch_lanes' occupancy target for pass 1 (k_walk_fast; SPX_CHUNK_GEOM_WAVES overrides:
+    // the geometry below was laid out for 20 wavefronts per CU until round 4 lowered the plain walk's default to 16 / 12 --
+    // 623 000 chunks on 262 144 lanes were 2.4 rounds)
+    static const int geom_waves_env = getenv("SPX_CHUNK_GEOM_WAVES") ? atoi(getenv("SPX_CHUNK_GEOM_WAVES")) : 0;
+    const bool side = mode == SPX_MODE_MS || args.out_docs != nullptr;
+    const int geom_waves = geom_waves_env > 0 ? geom_waves_env : (ix->waves_per_cu > 0 ? ix->waves_per_cu : (side ? 12 : 16));
+    const uint64_t lanes = (uint64_t)ix->num_cus * (uint64_t)geom_waves * 64;
     int mode_knob = ix->chunk_mode;                          // 0 automatic, 1 never, 2 always (tests)
     if (mode_knob == 1) return SPX_OK;
     // Chunk size (a multiple of the checkpoint spacing).  A seam closes within a few dozen characters
