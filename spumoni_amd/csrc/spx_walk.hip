@@ -1348,6 +1348,139 @@ __global__ void k_chunk_fix(const BatchArgs b) {
     }
 }
 
+// Pass 3 by wavefronts: one wavefront per read, one lane per chunk (top down, 64 chunks at a time).  What a
+// chunk hands to the chunk below it (k_chunk_fix's c_on / c_len / ...) is a function of what it was handed and of
+// its own records; the hand-overs die at the first reset, so instead of following the chain chunk by chunk every
+// lane computes its hand-over from its upper neighbour's, again and again until nothing changes (a chain that is
+// k chunks long settles in k rounds; the usual one in two).  Then every lane patches its own chunk.
+template <int MODE, bool DOC, bool NARROW>
+__global__ void k_chunk_fix_wave(const BatchArgs b) {
+    const uint64_t q = (blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (q >= b.nreads) return;
+    const uint64_t cs = b.ch.chunk_start[q], ce = b.ch.chunk_start[q + 1];
+    if (ce - cs < 2 || b.ch.read_fail[q]) return;
+    uint16_t* const len16 = reinterpret_cast<uint16_t*>(b.out_lengths);
+    uint16_t* const doc16 = reinterpret_cast<uint16_t*>(b.out_docs);
+    const uint8_t* const ch_flags = b.ch.flags - (b.offs[0] & ~7ull);
+    struct Carry {
+        uint32_t on;  // bit 0: counters, bit 1: document id
+        uint32_t len, doc;
+        uint64_t smp;
+    };
+    auto same = [](const Carry& x, const Carry& y) { return x.on == y.on && x.len == y.len && x.doc == y.doc && x.smp == y.smp; };
+    auto from_above = [&](const Carry& c, const Carry& first) {
+        Carry u;
+        u.on = __shfl_up(c.on, 1);
+        u.len = __shfl_up(c.len, 1);
+        u.doc = __shfl_up(c.doc, 1);
+        u.smp = ((uint64_t)__shfl_up((uint32_t)(c.smp >> 32), 1) << 32) | __shfl_up((uint32_t)c.smp, 1);
+        return lane == 0 ? first : u;
+    };
+    auto patch = [&](uint64_t from, uint64_t to, bool do_cnt, uint32_t dl, uint64_t ds, bool do_doc, uint32_t dv) {
+        bool cnt_reset = false, doc_reset = !DOC;
+        uint64_t w8 = 0, have = ~0ull;
+        for (uint64_t i = from; i-- > to;) {
+            if ((i & ~7ull) != have) {
+                have = i & ~7ull;
+                w8 = *reinterpret_cast<const uint64_t*>(ch_flags + have);
+            }
+            const uint32_t f = (uint32_t)(w8 >> ((i & 7) * 8)) & 0xffu;
+            if (!cnt_reset) {
+                if (f & 1) {
+                    cnt_reset = true;
+                } else if (do_cnt) {
+                    if (MODE == SPX_MODE_PML) {
+                        if (NARROW)
+                            len16[i] = (uint16_t)(len16[i] + dl);
+                        else
+                            b.out_lengths[i] += dl;
+                    } else {
+                        b.out_pointers[i] += ds;
+                    }
+                }
+            }
+            if (DOC && !doc_reset) {
+                if (f & 2) {
+                    doc_reset = true;
+                } else if (do_doc) {
+                    if (NARROW)
+                        doc16[i] = (uint16_t)dv;
+                    else
+                        b.out_docs[i] = dv;
+                }
+            }
+            if ((cnt_reset || !do_cnt) && (doc_reset || !do_doc)) break;
+        }
+    };
+    Carry first = {0, 0, 0, 0};  // handed to the tile's top chunk
+    for (uint64_t top = ce - 1; top > cs;) {  // chunks top - 1 down to max(cs, top - 64)
+        const uint64_t span = top - cs < 64 ? top - cs : 64;
+        const bool mine = lane < span;
+        const uint64_t j = top - 1 - (mine ? lane : 0);
+        const ChunkDesc d = b.ch.desc[j];
+        const SeamRec sr = b.ch.seams[j];
+        const uint64_t B = d.gend, A = B - (d.len & CHUNK_LEN_MASK);
+        const bool met = sr.met & 1, e_cnt = sr.reset_above & 1, e_doc = (sr.reset_above & 2) != 0;
+        // is there a reset among the speculative results [A, t)?  (only asked of chunks whose seam closed)
+        bool r_cnt = false, r_doc = !DOC;
+        if (mine && met) {
+            uint64_t w8 = 0, have = ~0ull;
+            for (uint64_t i = sr.t; i-- > A;) {
+                if ((i & ~7ull) != have) {
+                    have = i & ~7ull;
+                    w8 = *reinterpret_cast<const uint64_t*>(ch_flags + have);
+                }
+                const uint32_t f = (uint32_t)(w8 >> ((i & 7) * 8)) & 0xffu;
+                r_cnt |= (f & 1) != 0;
+                if (DOC) r_doc |= (f & 2) != 0;
+                if (r_cnt && r_doc) break;
+            }
+        }
+        uint32_t dl = 0, D_true = 0;
+        uint64_t ds = 0;
+        bool fix_cnt = false, fix_doc = false;
+        auto hand_over = [&](const Carry& in) {
+            const bool c_on = (in.on & 1) && !e_cnt, cd_on = (in.on & 2) && !e_doc;
+            Carry out;
+            if (!met) {
+                out.on = (c_on ? 1u : 0u) | (cd_on ? 2u : 0u);
+                out.len = in.len, out.smp = in.smp, out.doc = in.doc;
+                fix_cnt = fix_doc = false;
+                return out;
+            }
+            const uint32_t L_true = sr.ext.length + (c_on ? in.len : 0u);
+            const uint64_t S_true = sr.ext.sample + (c_on ? in.smp : 0ull);
+            D_true = cd_on ? in.doc : sr.ext.doc;
+            dl = L_true - sr.spec_length;
+            ds = S_true - sr.spec_sample;
+            fix_cnt = MODE == SPX_MODE_PML ? dl != 0 : ds != 0;
+            fix_doc = DOC && D_true != sr.spec_doc;
+            out.on = ((!r_cnt && fix_cnt) ? 1u : 0u) | ((DOC && !r_doc && fix_doc) ? 2u : 0u);
+            out.len = dl, out.smp = ds, out.doc = D_true;
+            return out;
+        };
+        Carry in = first, out = hand_over(lane == 0 ? first : Carry{0, 0, 0, 0});
+        for (int round = 0; round < 66; ++round) {
+            in = from_above(out, first);
+            const Carry nx = hand_over(in);
+            const bool changed = mine && !same(nx, out);
+            out = nx;
+            if (!__any(changed)) break;
+        }
+        if (mine) {
+            if (in.on) patch(B, sr.t, in.on & 1, in.len, in.smp, (in.on & 2) != 0, in.doc);  // pass-2 results [t, B)
+            if (met && (fix_cnt || fix_doc)) patch(sr.t, A, fix_cnt, dl, ds, fix_doc, D_true);  // speculative results [A, t)
+        }
+        const int last = (int)span - 1;
+        first.on = __shfl(out.on, last);
+        first.len = __shfl(out.len, last);
+        first.doc = __shfl(out.doc, last);
+        first.smp = ((uint64_t)__shfl((uint32_t)(out.smp >> 32), last) << 32) | __shfl((uint32_t)out.smp, last);
+        top -= span;
+    }
+}
+
 // bin-max classifier over finished lengths (compute_ms_pml.cpp:969-995): one wavefront per read,
 // one lane per bin
 template <bool NARROW>
@@ -1396,8 +1529,14 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
             a.ch, a.nreads, (uint32_t)round, a.ch.last_round, a.counters);
         SPX_HIP(hipGetLastError());
     }
-    const unsigned grid = (unsigned)((a.nreads + WALK_TPB - 1) / WALK_TPB);
-    k_chunk_fix<MODE, DOC, NARROW><<<grid, WALK_TPB, 0, stream>>>(a);
+    static const bool fix_by_lanes = getenv("SPX_CHUNK_FIX_LANES") != nullptr;  // the round-3 kernel, for A/B
+    if (fix_by_lanes) {
+        const unsigned grid = (unsigned)((a.nreads + WALK_TPB - 1) / WALK_TPB);
+        k_chunk_fix<MODE, DOC, NARROW><<<grid, WALK_TPB, 0, stream>>>(a);
+    } else {
+        const unsigned grid = (unsigned)((a.nreads * 64 + WALK_TPB - 1) / WALK_TPB);
+        k_chunk_fix_wave<MODE, DOC, NARROW><<<grid, WALK_TPB, 0, stream>>>(a);
+    }
     SPX_HIP(hipGetLastError());
     if (MODE == SPX_MODE_PML && a.out_class != nullptr) {
         const unsigned cgrid = (unsigned)((a.nreads * 64 + WALK_TPB - 1) / WALK_TPB);
