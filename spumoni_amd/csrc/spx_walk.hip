@@ -1100,8 +1100,10 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     // the plain walk over compact rows has a body of its own (spx_walk_fast.inc); SPX_OLD_WALK=1 keeps the state
     // machine for it too (A/B runs, and the tests that hold the two against each other)
     static const bool old_walk = getenv("SPX_OLD_WALK") != nullptr;
-    constexpr int FCHUNK = CHUNK == 1 ? 1 : 0;  // k_walk_fast also walks pass 1 of the chunked walk; pass 2 is the state machine's
-    const bool fast = COMPACT && CHUNK <= 1 && args.only_flagged == nullptr && !old_walk && items < (1ull << 31);
+    // k_walk_fast also walks passes 1 and 2 of the chunked walk (SPX_PASS2_LANES=1: pass 2 on the state machine, for A/B runs)
+    static const bool pass2_lanes = getenv("SPX_PASS2_LANES") != nullptr;
+    constexpr int FCHUNK = CHUNK;
+    const bool fast = COMPACT && !(CHUNK == 2 && pass2_lanes) && args.only_flagged == nullptr && !old_walk && items < (1ull << 31);
     if (args.in_starts != nullptr && !(fast && CHUNK == 0)) {
         set_error("internal: parked reads (BatchArgs::in_starts) are taken by the plain k_walk_fast only");
         return SPX_E_ARG;
