@@ -1519,6 +1519,102 @@ __global__ void k_classify_reads(const BatchArgs b) {
     if (lane == 0) b.out_class[q] = spx_class{sum, above, below};
 }
 
+// The same classifier reading the lengths the way they lie: a wavefront per read goes over it in tiles of 64 x E
+// consecutive values, a lane takes E of them in one 16-byte load (they span two bins at most: bin_width >= E), the
+// bins' maxima are collected in LDS (ds_max), and the bins that end inside the tile are judged by one lane each;
+// the tile's last bin goes on into the next tile.  (k_classify_reads gives a lane a bin: 300-byte strides, 14 of 64
+// lanes busy for a 2 200-character read -- 1.4 TB/s; this one reads at the rate of a copy.)
+template <bool NARROW>
+__global__ void __launch_bounds__(WALK_TPB) k_classify_tiles(const BatchArgs b) {
+    constexpr uint32_t E = NARROW ? 8 : 4;
+    constexpr uint32_t TILE = 64 * E;
+    __shared__ uint32_t s_bins[WALK_TPB / 64][TILE / E + 8];
+    const uint64_t q = (blockIdx.x * (uint64_t)WALK_TPB + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (q >= b.nreads) return;
+    uint32_t* const sb = s_bins[threadIdx.x >> 6];
+    const uint64_t base = b.offs[q], m = b.offs[q + 1] - base, end_all = b.offs[b.nreads];
+    const uint64_t w = b.bin_width ? b.bin_width : 1;
+    const uint64_t nb = m / w > 0 ? m / w : 1;
+    const uint8_t* const lens = reinterpret_cast<const uint8_t*>(b.out_lengths);
+    auto bin_of = [&](uint64_t i) {  // min(i / w, nb - 1)
+        const uint64_t d = w > 1 ? __umul64hi(i, b.bin_magic) : i;
+        return d < nb - 1 ? d : nb - 1;
+    };
+    uint32_t above = 0, below = 0;
+    uint64_t sum = 0;
+    for (uint32_t t = lane; t < TILE / E + 8; t += 64) sb[t] = 0;
+    for (uint64_t t0 = 0; t0 < m; t0 += TILE) {
+        const uint64_t first_bin = bin_of(t0);
+        const uint64_t t_end = t0 + TILE < m ? t0 + TILE : m;
+        const uint64_t last_bin = bin_of(t_end - 1);
+        const uint64_t i0 = t0 + (uint64_t)lane * E;
+        if (i0 < m) {
+            uint32_t v[E];
+            const uint64_t gi = base + i0;
+            if (gi + E <= end_all) {
+                uint32_t raw[4];
+                __builtin_memcpy(raw, lens + gi * (NARROW ? 2 : 4), 16);
+#pragma unroll
+                for (uint32_t e = 0; e < E; ++e) v[e] = NARROW ? (raw[e >> 1] >> ((e & 1) * 16)) & 0xffffu : raw[e];
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < E; ++e)
+                    v[e] = gi + e < end_all ? (NARROW ? (uint32_t)reinterpret_cast<const uint16_t*>(lens)[gi + e]
+                                                      : reinterpret_cast<const uint32_t*>(lens)[gi + e])
+                                            : 0u;
+            }
+            const uint64_t ba = bin_of(i0);
+            const uint64_t cut = ba + 1 < nb ? (ba + 1) * w : ~0ull;  // first index of the next bin (the last bin takes the rest)
+            uint32_t ma = 0, mb = 0;
+            bool any_b = false;
+#pragma unroll
+            for (uint32_t e = 0; e < E; ++e) {
+                const uint64_t i = i0 + e;
+                if (i < m) {
+                    if (i < cut) {
+                        ma = v[e] > ma ? v[e] : ma;
+                    } else {
+                        mb = v[e] > mb ? v[e] : mb;
+                        any_b = true;
+                    }
+                }
+            }
+            atomicMax(&sb[ba - first_bin], ma);
+            if (any_b) atomicMax(&sb[ba + 1 - first_bin], mb);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the bins that ended inside the tile: all below the bin the next tile starts in (all of them when the read ends here)
+        const bool read_ends = t_end == m;
+        const uint64_t next_first = read_ends ? last_bin + 1 : bin_of(t_end);
+        const uint64_t done = next_first - first_bin;
+        const uint32_t carry = next_first == last_bin ? sb[last_bin - first_bin] : 0u;
+        for (uint64_t t = lane; t < done; t += 64) {
+            const uint32_t mx = sb[t];
+            if (mx >= b.max_value_thr)
+                above++;
+            else
+                below++;
+            sum += mx;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint64_t t = lane; t <= last_bin - first_bin; t += 64) sb[t] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) sb[0] = carry;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        above += __shfl_xor(above, sft);
+        below += __shfl_xor(below, sft);
+        sum += __shfl_xor(sum, sft);
+    }
+    if (lane == 0) b.out_class[q] = spx_class{sum, above, below};
+}
+
 template <int MODE, bool DOC, bool NARROW>
 int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) {
     int rc;
@@ -1542,7 +1638,11 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
     SPX_HIP(hipGetLastError());
     if (MODE == SPX_MODE_PML && a.out_class != nullptr) {
         const unsigned cgrid = (unsigned)((a.nreads * 64 + WALK_TPB - 1) / WALK_TPB);
-        k_classify_reads<NARROW><<<cgrid, WALK_TPB, 0, stream>>>(a);
+        static const bool by_bins = getenv("SPX_CLASSIFY_BY_BINS") != nullptr;  // the round-2 kernel, for A/B
+        if (a.bin_width >= 8 && !by_bins)
+            k_classify_tiles<NARROW><<<cgrid, WALK_TPB, 0, stream>>>(a);
+        else
+            k_classify_reads<NARROW><<<cgrid, WALK_TPB, 0, stream>>>(a);
         SPX_HIP(hipGetLastError());
     }
     // reads in which a seam did not close: the plain walk (rare; results and class are overwritten)

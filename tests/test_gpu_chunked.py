@@ -215,3 +215,39 @@ def test_device_path_with_nonzero_first_offset(oracle_mod, shift_by, mode_doc):
         want = orc.ms(hs, ho, want_docs=True)
         assert np.array_equal(d_ptr[sl].cpu().numpy().view(np.uint64), want["pointers"])
         assert np.array_equal(d_doc[sl].cpu().numpy().view(np.uint32), want["docs"])
+
+
+@pytest.mark.parametrize("out_dtype", [torch.int16, torch.int32])
+def test_classifier_of_chunked_batches_over_bin_widths(oracle_mod, out_dtype):
+    """The classifier that follows the chunked walk (k_classify_tiles: tiles of 512 / 256 lengths, bins collected in LDS; bins
+    narrower than 8 stay on the lane-per-bin kernel): bins narrower than, equal to, not dividing and wider than a tile, wider
+    than a read, reads of ragged lengths (a last bin that takes the remainder, reads shorter than a bin, empty reads), against
+    the oracle's classifier over the oracle's lengths."""
+    raw = synth.statistical_rlbwt(1 << 16, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    ix = _chunked(capi.Index.from_raw(raw, 0), 128)
+    orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
+    seqs, offs = synth.simulate_reads(raw, 400, 2200, seed=5)
+    # ragged: cut every read to a length of its own (0 .. 2200), keeping the characters where they are
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 2201, size=400)
+    lens[:6] = [0, 1, 7, 8, 511, 513]
+    o_h = offs.cpu().numpy()
+    s_h = seqs.cpu().numpy()
+    parts = [s_h[o_h[i]: o_h[i] + lens[i]] for i in range(400)]
+    s2 = np.concatenate(parts).astype(np.uint8)
+    o2 = np.zeros(401, dtype=np.uint64)
+    o2[1:] = np.cumsum(lens)
+    want = orc.pml(s2, o2)
+    d_seqs = capi.pad_seqs(torch.from_numpy(s2).cuda())
+    d_offs = torch.from_numpy(o2.view(np.int64)).cuda()
+    for w in (1, 5, 8, 9, 16, 37, 150, 256, 512, 513, 1000, 2199, 2200, 5000):
+        for thr in (1, 5):
+            d_len = torch.empty(s2.size + 8, dtype=out_dtype, device="cuda")
+            d_cls = torch.empty((400, 2), dtype=torch.int64, device="cuda")
+            ix.query_device(capi.SPX_MODE_PML, d_seqs, d_offs, int(s2.size), d_lengths=d_len, d_class=d_cls, bin_width=w, max_value_thr=thr)
+            torch.cuda.synchronize()
+            assert ix.last_chunk_stats()["chunk_len"] == 128
+            f, a, b, s = oracle_mod.classify(want, o2, w, thr)
+            c32 = d_cls.view(torch.int32).view(400, 4).cpu().numpy()
+            assert np.array_equal(c32[:, 2].view(np.uint32), a) and np.array_equal(c32[:, 3].view(np.uint32), b), (w, thr)
+            assert np.array_equal(d_cls[:, 0].cpu().numpy().view(np.uint64), s), (w, thr)
