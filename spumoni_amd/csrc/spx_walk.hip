@@ -1160,7 +1160,8 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         // SIMD, and only as many active lanes per wavefront as needed -- a wavefront whose few
         // lanes sit in the same phase issues a fraction of the instructions per iteration.
         tpb = 64;
-        const uint64_t waves = (uint64_t)ix->num_cus * 4;  // one wavefront per SIMD
+        static const int spread = getenv("SPX_SPREAD_WAVES") ? atoi(getenv("SPX_SPREAD_WAVES")) : 1;
+        const uint64_t waves = (uint64_t)ix->num_cus * 4 * (uint64_t)(spread > 0 ? spread : 1);  // wavefronts per SIMD to fill
         uint64_t lpw = (items + waves - 1) / waves;
         if (lpw < 1) lpw = 1;
         if (lpw > 64) lpw = 64;
