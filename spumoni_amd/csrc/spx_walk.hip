@@ -1160,13 +1160,19 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         // SIMD, and only as many active lanes per wavefront as needed -- a wavefront whose few
         // lanes sit in the same phase issues a fraction of the instructions per iteration.
         tpb = 64;
-        static const int spread = getenv("SPX_SPREAD_WAVES") ? atoi(getenv("SPX_SPREAD_WAVES")) : 1;
+        // (two per SIMD: 1.12 -> 1.10 ms for the 6 250-read share at r = 2e9, 0.87 -> 0.85 at r = 2^27; three and four are
+        // slower again -- profiles/r04_c5_passes.txt)
+        static const int spread = getenv("SPX_SPREAD_WAVES") ? atoi(getenv("SPX_SPREAD_WAVES")) : 2;
         const uint64_t waves = (uint64_t)ix->num_cus * 4 * (uint64_t)(spread > 0 ? spread : 1);  // wavefronts per SIMD to fill
         uint64_t lpw = (items + waves - 1) / waves;
         if (lpw < 1) lpw = 1;
         if (lpw > 64) lpw = 64;
         a.lanes_per_wave = (uint32_t)lpw;
         grid = (items + lpw - 1) / lpw;
+        if (spread > 1) {  // (blocks of four wavefronts: a 64-thread block costs the LDS of a 256-thread one, 13 fit a CU)
+            tpb = WALK_TPB;
+            grid = (items + lpw * 4 - 1) / (lpw * 4);
+        }
     }
     // Reads are dealt by striding (rd += lanes): when the batch is a small multiple of the lanes, the last round leaves most of
     // them idle while a few finish (1.25 M reads on 262 144 lanes: 4.77 reads per lane, a fifth round for three lanes in four).
