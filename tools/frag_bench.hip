@@ -48,25 +48,35 @@ __global__ void __launch_bounds__(256) k_chase(const uint4* __restrict__ tab, ui
     if (acc == 0x1234567) sink[0] = acc;
 }
 
-static double chase(const uint4* tab, uint64_t bytes, uint64_t* sink, int ncu) {
+static double chase(const uint4* tab, uint64_t bytes, uint64_t* sink, int ncu, int blocks_per_cu = 4, double* ns = nullptr, unsigned tpb = 256) {
     const int iters = 400;
-    const unsigned grid = (unsigned)ncu * 4;  // 16 wavefronts per CU: the walk's occupancy
+    const unsigned grid = (unsigned)ncu * blocks_per_cu;  // 4 x 256 threads: 16 wavefronts per CU, the walk's occupancy; 1 x 64: one per CU (latency)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    k_chase<<<grid, 256>>>(tab, bytes / 16, 50, sink);
+    k_chase<<<grid, tpb>>>(tab, bytes / 16, 50, sink);
     double best = 0;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        k_chase<<<grid, 256>>>(tab, bytes / 16, iters, sink);
+        k_chase<<<grid, tpb>>>(tab, bytes / 16, iters, sink);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        const double rate = (double)grid * 256 * iters / ms / 1e6;
-        if (rate > best) best = rate;
+        const double rate = (double)grid * tpb * iters / ms / 1e6;
+        if (rate > best) {
+            best = rate;
+            if (ns) *ns = ms * 1e6 / iters;
+        }
     }
     return best;
+}
+
+static void both(const char* what, const uint4* t, uint64_t bytes, uint64_t* sink, int ncu) {
+    double ns1 = 0, ns4 = 0;
+    const double r4 = chase(t, bytes, sink, ncu, 4, &ns4), r1 = chase(t, bytes, sink, ncu, 1, &ns1, 64);
+    printf("%-52s: %6.2f G gathers/s at 16 wavefronts per CU (%4.0f ns per dependent gather); one wavefront per CU: %5.2f G/s, %4.0f ns\n", what, r4, ns4, r1, ns1);
+    fflush(stdout);
 }
 
 int main(int argc, char** argv) {
@@ -85,8 +95,9 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&t, gb << 30));
         k_fill<<<65536, 256>>>(t, (gb << 30) / 16);
         CK(hipDeviceSynchronize());
-        printf("fresh device, one allocation of %3llu GB : %6.2f G gathers/s\n", (unsigned long long)gb, chase(t, gb << 30, sink, ncu));
-        fflush(stdout);
+        char what[96];
+        snprintf(what, sizeof what, "fresh device, one allocation of %3llu GB", (unsigned long long)gb);
+        both(what, t, gb << 30, sink, ncu);
         CK(hipFree(t));
     }
     // fill the device: one big block, then pieces over 2 x the table's size (+ slack); free every other piece
@@ -112,14 +123,17 @@ int main(int argc, char** argv) {
     }
     k_fill<<<65536, 256>>>(t, tab2 / 16);
     CK(hipDeviceSynchronize());
-    printf("table of %llu GB from %llu MB holes          : %6.2f G gathers/s\n", (unsigned long long)(tab2 >> 30),
-           (unsigned long long)(piece >> 20), chase(t, tab2, sink, ncu));
+    {
+        char what[96];
+        snprintf(what, sizeof what, "table of %llu GB from %llu MB holes", (unsigned long long)(tab2 >> 30), (unsigned long long)(piece >> 20));
+        both(what, t, tab2, sink, ncu);
+    }
     CK(hipFree(t));
     for (size_t i = 1; i < ps.size(); i += 2) CK(hipFree(ps[i]));
     if (fill) CK(hipFree(fill));
     CK(hipMalloc(&t, tab2));
     k_fill<<<65536, 256>>>(t, tab2 / 16);
     CK(hipDeviceSynchronize());
-    printf("everything freed, the same table again      : %6.2f G gathers/s\n", chase(t, tab2, sink, ncu));
+    both("everything freed, the same table again", t, tab2, sink, ncu);
     return 0;
 }
