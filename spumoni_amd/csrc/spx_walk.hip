@@ -1146,6 +1146,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     const uint64_t need = (items + WALK_TPB - 1) / WALK_TPB;
     BatchArgs a = args;
     a.lanes_per_wave = 64;
+    bool small_batch = false;  // fewer items than resident lanes
     if (ix->force_lanes_per_wave > 0) {
         // experiment knob: 1 = the "one wavefront owns one read" mapping
         const uint64_t lpw = (uint64_t)(ix->force_lanes_per_wave > 64 ? 64 : ix->force_lanes_per_wave);
@@ -1160,6 +1161,7 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
         // SIMD, and only as many active lanes per wavefront as needed -- a wavefront whose few
         // lanes sit in the same phase issues a fraction of the instructions per iteration.
         tpb = 64;
+        small_batch = true;
         // (two per SIMD: 1.12 -> 1.10 ms for the 6 250-read share at r = 2e9, 0.87 -> 0.85 at r = 2^27; three and four are
         // slower again -- profiles/r04_c5_passes.txt)
         static const int spread = getenv("SPX_SPREAD_WAVES") ? atoi(getenv("SPX_SPREAD_WAVES")) : 2;
@@ -1187,7 +1189,14 @@ int launch_lanes(spx_index* ix, const BatchArgs& args, hipStream_t stream, uint6
     }
     if (grid == 0) grid = 1;
     if (fast) {
-        k_walk_fast<MODE, DOC, NARROW, FCHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+        // (a launch that does not fill the chip, and pass 2 -- a few characters per chunk, then a long tail -- are latency
+        // chains: they take the body that issues its gather early; SPX_EARLY_GATHER=0 / 1 forces either, for A/B runs)
+        static const int early_env = getenv("SPX_EARLY_GATHER") ? atoi(getenv("SPX_EARLY_GATHER")) : -1;
+        const bool early = early_env >= 0 ? early_env != 0 : (FCHUNK == 2 || small_batch);
+        if (early)
+            k_walk_fast<MODE, DOC, NARROW, FCHUNK, true><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
+        else
+            k_walk_fast<MODE, DOC, NARROW, FCHUNK, false><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
         if (wrote_lengths) *wrote_lengths = MODE == SPX_MODE_PML;  // no bit mask, no expansion kernel
     } else
         k_walk_lanes<MODE, DOC, COMPACT, NARROW, CHUNK><<<(unsigned)grid, tpb, 0, stream>>>(ix->view, a);
