@@ -239,6 +239,15 @@ int spx_last_chunk_stats(spx_index *ix, uint64_t out[4]);
 void *spx_host_alloc(size_t bytes);
 void spx_host_free(void *p);
 
+/* Page-locks memory the CALLER owns, for the same purpose.  What it is for: the harness maps the tail of an output
+ * file (the ofstream of compute_ms_pml.cpp:1001-1010 in the reference) and registers the mapping, so that
+ * spx_query_text_fetch lands the text in the file's page-cache pages directly -- no staging buffer, no write() --
+ * at the link's rate (profiles/r05_drain_hip.txt: 57 GB/s into a tmpfs file against 6.5 GB/s for pwrite).  Works for
+ * anonymous memory and for shared mappings of tmpfs files; a file system whose pages cannot be pinned makes it fail
+ * with SPX_E_HIP, and the caller copies instead.  spx_host_unregister before the memory is unmapped.          */
+int spx_host_register(void *p, size_t bytes);
+int spx_host_unregister(void *p);
+
 /* ---- minimizer digestion (run -m / -a) -------------------------------------
  * Replaces perform_minimizer_digestion / perform_dna_minimizer_digestion
  * (src/spumoni.cpp:294-319, 321-342), which the harness applies to every read

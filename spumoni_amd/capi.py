@@ -38,6 +38,8 @@ EXPORTS = [
     "spx_set_option",
     "spx_host_alloc",
     "spx_host_free",
+    "spx_host_register",
+    "spx_host_unregister",
     "spx_digest_capacity",
     "spx_digest_batch",
     "spx_digest_batch_device",
@@ -131,6 +133,10 @@ def lib() -> C.CDLL:
         L.spx_host_alloc.restype = vp
         L.spx_host_alloc.argtypes = [C.c_size_t]
         L.spx_host_free.argtypes = [vp]
+        L.spx_host_register.restype = i32
+        L.spx_host_register.argtypes = [vp, C.c_size_t]
+        L.spx_host_unregister.restype = i32
+        L.spx_host_unregister.argtypes = [vp]
         u32 = C.c_uint32
         L.spx_digest_capacity.restype = u64
         L.spx_digest_capacity.argtypes = [i32, u32, u64]

@@ -1,5 +1,7 @@
 #include "classify.hpp"
 
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -14,8 +16,10 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -132,35 +136,53 @@ void IndexSet::load(const RunOptions& o) {
     }
     ix.push_back(first);
     if (spx_index_stats(first, &n, &r) != SPX_OK) fatal_error("%s", spx_last_error());
-    // Replicas: flatten once, copy N - 1 times -- as a doubling tree (device 0 -> 1; 0 -> 2, 1 -> 3; 0 -> 4 ... 3 -> 7), the
-    // copies of a round on threads of their own: every copy has its own source and, on an xGMI node, its own link, so
-    // seven replicas of a 200 GB index cost three copy times instead of seven
-    const size_t ndev = o.devices.size();
+    // Replicas: flatten once, copy to every OTHER device once -- as a doubling tree (device 0 -> 1; 0 -> 2, 1 -> 3; 0 -> 4 ...
+    // 3 -> 7), the copies of a round on threads of their own: every copy has its own source and, on an xGMI node, its own
+    // link, so seven replicas of a 200 GB index cost three copy times instead of seven.  An entry of the
+    // device list that names a device a second time is a second WORKER on it: a query context of its own (scratch,
+    // stream, counters) over the arrays that are already there (spx_index_clone onto the same device copies nothing).
+    const std::vector<int> devs = o.devices.empty() ? std::vector<int>{0} : o.devices;
+    const size_t nwork = devs.size();
     const auto t_all = std::chrono::steady_clock::now();
-    ix.resize(std::max<size_t>(ndev, 1), nullptr);
-    for (size_t have = 1; have < ndev;) {
-        const size_t nnew = std::min(have, ndev - have);
+    ix.resize(nwork, nullptr);
+    std::vector<size_t> uniq;  // workers that are the first on their device
+    for (size_t i = 0; i < nwork; ++i) {
+        bool seen = false;
+        for (size_t j : uniq) seen = seen || devs[j] == devs[i];
+        if (!seen) uniq.push_back(i);
+    }
+    for (size_t have = 1; have < uniq.size();) {
+        const size_t nnew = std::min(have, uniq.size() - have);
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::string> errs(nnew);
         std::vector<std::thread> th;
         for (size_t i = 0; i < nnew; ++i)
             th.emplace_back([&, i] {
-                spx_index* p = spx_index_clone(ix[i], o.devices[have + i]);
+                spx_index* p = spx_index_clone(ix[uniq[i]], devs[uniq[have + i]]);
                 if (!p) errs[i] = spx_last_error();
-                ix[have + i] = p;
+                ix[uniq[have + i]] = p;
             });
         for (auto& t : th) t.join();
         for (size_t i = 0; i < nnew; ++i) {
-            if (!ix[have + i]) fatal_error("%s", errs[i].c_str());
-            std::fprintf(stderr, "[timing] index replica on device %d (copied from device %d)\n", o.devices[have + i], o.devices[i]);
+            if (!ix[uniq[have + i]]) fatal_error("%s", errs[i].c_str());
+            std::fprintf(stderr, "[timing] index replica on device %d (copied from device %d)\n", devs[uniq[have + i]], devs[uniq[i]]);
         }
         std::fprintf(stderr, "[timing] %zu replica%s in parallel  %.3f s\n", nnew, nnew > 1 ? "s" : "",
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         have += nnew;
     }
-    if (ndev > 1)
-        std::fprintf(stderr, "[timing] all %zu index replicas  %.3f s\n", ndev - 1,
+    if (uniq.size() > 1)
+        std::fprintf(stderr, "[timing] all %zu index replicas  %.3f s\n", uniq.size() - 1,
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count());
+    for (size_t i = 1; i < nwork; ++i) {
+        if (ix[i]) continue;
+        size_t src = 0;
+        for (size_t j : uniq)
+            if (devs[j] == devs[i]) src = j;
+        ix[i] = spx_index_clone(ix[src], devs[i]);
+        if (!ix[i]) fatal_error("%s", spx_last_error());
+        std::fprintf(stderr, "[timing] worker %zu: a second query context on device %d (shares the arrays of worker %zu)\n", i, devs[i], src);
+    }
 }
 
 size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promotions, bool use_dna_letters) {
@@ -327,11 +349,16 @@ struct SuperBatch {
     std::vector<std::string_view> ids;  // views into the mapped reads file (or into own_ids)
     std::deque<std::string> own_ids;    // general-text reads are named here (a deque: addresses stay put)
     PinnedBuf<uint8_t> seqs;
-    std::vector<uint64_t> offs{0};
+    PinnedBuf<uint64_t> offs;           // nreads + 1 entries (page-locked: they travel to the device with the reads)
+    PinnedBuf<uint32_t> gap;            // per read: bytes of its ">id\n" line (what the device leaves free in front of its values)
+    uint64_t longest = 0;               // longest read
+    SuperBatch() { offs.assign(1, 0); }
     void clear() {
         ids.clear();
         own_ids.clear();
         seqs.n = 0;
+        gap.n = 0;
+        longest = 0;
         offs.assign(1, 0);
     }
     size_t nreads() const { return ids.size(); }
@@ -354,14 +381,20 @@ struct Results {
     bool device_text = false;
     uint32_t streams = 0;  // SPX_TEXT_* present in text[]
     PinnedBuf<char> text[3];
+    char* text_at[3] = {nullptr, nullptr, nullptr};  // where stream i's text is: text[i], or memory of the output file itself
     PinnedBuf<uint64_t> line_start[3];
-    std::vector<uint32_t> gap;
 };
 
-// One super-batch on one device (the worker thread of that device calls this): the batch form of the
+// One super-batch on one device (a worker thread of that device calls this): the batch form of the
 // reference's loop body -- [digestion +] matching_statistics + bin classification
-// (compute_ms_pml.cpp:916-995).
-void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, size_t max_value_thr, Results& res) {
+// (compute_ms_pml.cpp:916-995).  Only what the chosen path hands back is allocated (round 4 reserved the 16-bit value
+// buffers on the text path as well: 128 MB of pages locked per slot for nothing, 10 of its 16 ms per super-batch).
+// place(bytes, dest): called once per super-batch, between the walk and the copy-out on the text path (the streams' sizes
+// are known then) and right away on the other paths (bytes all zero): the harness reserves the super-batch's place in every
+// output file there, in input order, and may name, per stream, memory of the file itself for the text to land in
+// (dest[i] stays null: the slot's page-locked buffer is used and a writer thread copies it).
+using PlaceFn = std::function<void(const uint64_t bytes[3], char* dest[3])>;
+void run_on_device(spx_index* ix, const RunOptions& o, SuperBatch& sb, size_t max_value_thr, Results& res, const PlaceFn& place) {
     const size_t nreads = sb.nreads();
     const uint64_t total = sb.offs.back();
     const bool digest = o.use_promotions || o.use_dna_letters;
@@ -369,20 +402,8 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     // with digestion the results are laid out at the digested offsets, inside a region as large as
     // the worst case (every k-mer reported: 1 byte each for -m, k letters for -a)
     const uint64_t grow = digest && o.use_dna_letters ? (uint64_t)o.k : 1;
-    uint64_t longest = 0;
-    for (size_t q = 0; q < nreads; ++q) longest = std::max<uint64_t>(longest, sb.offs[q + 1] - sb.offs[q]);
-    res.narrow = !digest && longest < 65536;
-    if (res.narrow) {
-        res.lengths16.resize_uninit(total + 8);
-        if (o.use_doc) res.docs16.resize_uninit(total + 8);
-    } else {
-        res.lengths.resize_uninit(total * grow);
-        if (o.use_doc) res.docs.resize_uninit(total * grow);
-    }
-    if (o.ms) res.pointers.resize_uninit(total * grow);
+    res.narrow = !digest && sb.longest < 65536;
     if (o.write_report) res.cls.resize_uninit(nreads);
-    res.beg.resize(nreads);
-    res.end.resize(nreads);
     int rc;
     // SPUMONI_HOST_FORMAT=1: values over PCIe, digits on the host cores (the round-2 path; A/B runs and tests)
     static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
@@ -393,36 +414,58 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     if (res.device_text) {
         // the output files' text is written on the device (compute_ms_pml.cpp:1001-1010, 1182-1205): what comes back
         // over PCIe is the files' new tail, with room for every ">id\n"
-        res.gap.resize(nreads);
-        for (size_t q = 0; q < nreads; ++q) res.gap[q] = (uint32_t)sb.ids[q].size() + 2;
         uint64_t bytes[3] = {0, 0, 0};
         rc = spx_query_text_begin(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, digest ? kind : 0, (uint32_t)o.k, (uint32_t)o.w,
-                                  sb.seqs.data(), sb.offs.data(), nreads, res.gap.data(), streams,
+                                  sb.seqs.data(), sb.offs.data(), nreads, sb.gap.data(), streams,
                                   o.write_report ? res.cls.data() : nullptr, o.bin_size, max_value_thr, bytes);
         if (rc != SPX_OK) fatal_error("%s", spx_last_error());
         char* tp[3] = {nullptr, nullptr, nullptr};
         uint64_t* lp[3] = {nullptr, nullptr, nullptr};
+        place(bytes, tp);
         int first = -1;
         for (int i = 0; i < 3; ++i) {
+            res.text_at[i] = nullptr;
             if (!(streams & (1u << i))) continue;
             if (first < 0) first = i;
-            res.text[i].resize_uninit(bytes[i] + 1);
+            if (!tp[i]) {
+                res.text[i].resize_uninit(bytes[i] + 1);
+                tp[i] = res.text[i].data();
+            }
+            res.text_at[i] = tp[i];
             res.line_start[i].resize_uninit(nreads + 1);
-            tp[i] = res.text[i].data();
             lp[i] = res.line_start[i].data();
         }
         rc = spx_query_text_fetch(ix, tp, lp);
         if (rc != SPX_OK) fatal_error("%s", spx_last_error());
-        const uint64_t* ls = res.line_start[first].data();
-        for (size_t q = 0; q < nreads; ++q) {  // (a read without values: its record is the header and a newline)
-            res.beg[q] = 0;
-            res.end[q] = ls[q + 1] - ls[q] - res.gap[q] - 1;
+        if (digest) {  // (only a digested read can come back without values: the worker looks for the first one)
+            res.beg.resize(nreads);
+            res.end.resize(nreads);
+            const uint64_t* ls = res.line_start[first].data();
+            for (size_t q = 0; q < nreads; ++q) {  // (a read without values: its record is the header and a newline)
+                res.beg[q] = 0;
+                res.end[q] = ls[q + 1] - ls[q] - sb.gap[q] - 1;
+            }
         }
         return;
     }
+    {
+        const uint64_t none[3] = {0, 0, 0};
+        char* unused[3] = {nullptr, nullptr, nullptr};
+        place(none, unused);
+    }
+    res.beg.resize(nreads);
+    res.end.resize(nreads);
+    // SPUMONI_REPORT_ONLY (PML): the per-character values are neither written nor copied back
+    const bool no_len = o.report_only && !o.ms && o.write_report;
+    if (res.narrow) {
+        if (!no_len) res.lengths16.resize_uninit(total + 8);
+        if (o.use_doc) res.docs16.resize_uninit(total + 8);
+    } else {
+        if (!no_len || digest) res.lengths.resize_uninit(total * grow);
+        if (o.use_doc) res.docs.resize_uninit(total * grow);
+    }
+    if (o.ms) res.pointers.resize_uninit(total * grow);
     if (!digest) {
-        // SPUMONI_REPORT_ONLY (PML): the per-character values are neither written nor copied back
-        const bool no_len = o.report_only && !o.ms && o.write_report;
         if (res.narrow)
             rc = spx_query_batch16(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, sb.seqs.data(), sb.offs.data(), nreads,
                                    no_len ? nullptr : res.lengths16.data(), o.ms ? res.pointers.data() : nullptr,
@@ -455,14 +498,23 @@ void run_on_device(spx_index* ix, const RunOptions& o, const SuperBatch& sb, siz
     if (rc != SPX_OK) fatal_error("%s", spx_last_error());
 }
 
-// The four output files as plain descriptors with a running end offset each: a super-batch is
-// formatted by several host threads into their own buffers, the buffers' sizes are prefix-summed,
-// and every thread pwrite()s its part at its own offset -- no concatenation, no serial write.
-// (Copying the parts into a shared mapping of the file's new tail instead was tried: on tmpfs 0.69 s against
-// 0.54 s for 2 GB -- allocating the file's pages is what takes the time, whichever way they are touched.)
+// The output files.  Writes to ONE file serialise on its inode lock whatever the number of writing threads
+// (tools/drain_bench.cpp on the GPU box, profiles/r05_drain_bench.txt: one thread puts 6.5-7 GB/s of fresh pages into a
+// tmpfs file, sixteen threads 3.4, sixteen threads into sixteen FILES 58) -- a 2 GB .pseudo_lengths cannot take more than
+// 13 M reads/s that way.  So the file's tail is prepared as MEMORY while the index loads (prepare_outputs): allocated
+// (fallocate), mapped and populated, and page-locked for the device (spx_host_register); the text of a super-batch is then
+// copied by the device straight into the file's pages, at its place in input order (profiles/r05_drain_hip.txt: 57 GB/s
+// -- the link), the ">id" lines and the report are written into the mapping by the pool, and nothing goes through write()
+// at all.  What does not fit the prepared tail (the estimate was short), a file system that cannot be mapped, host-
+// formatted runs: one writer thread per file with pwrite, as before, the files side by side.
 struct OutFile {
     int fd = -1;
-    uint64_t end = 0;
+    uint64_t end = 0;          // logical size: everything below is final (batches complete in input order)
+    uint64_t reserved = 0;     // device-text runs: where the next super-batch's share starts (OffsetOrder)
+    char* map = nullptr;       // the file's first map_size bytes as memory (MAP_SHARED), or null
+    uint64_t map_size = 0;
+    bool pinned = false;       // ... and page-locked: the device writes it
+    std::string temp_path;     // prepared ahead of time under this name, renamed when the run starts
     void open(const std::string& path) {
         // A large output of an earlier run under the same name: truncating it gives its pages back synchronously
         // (0.2 s for 2 GB on tmpfs, inside "processing the patterns").  It is moved aside and removed on a thread
@@ -470,12 +522,23 @@ struct OutFile {
         struct stat st;
         // (lstat: a symbolic link is left alone and its target truncated as before; the old file is registered, so that an
         // early exit removes it too)
-        if (::lstat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > (64 << 20)) {
+        const bool regular = ::lstat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+        if (regular && st.st_size > (64 << 20)) {
             const std::string old = path + ".old." + std::to_string((long)::getpid());
             if (::rename(path.c_str(), old.c_str()) == 0) {
                 register_leftover(old);
                 std::thread([old] { ::unlink(old.c_str()); }).detach();
             }
+        }
+        if (fd >= 0) {
+            // prepared under another name: it takes the name now (where the name is a symbolic link or something else that
+            // is not a plain file the prepared file is dropped and the target opened as always)
+            const bool plain_target = ::lstat(path.c_str(), &st) != 0 || S_ISREG(st.st_mode);
+            if (plain_target && ::rename(temp_path.c_str(), path.c_str()) == 0) return;
+            drop_mapping();
+            ::close(fd);
+            ::unlink(temp_path.c_str());
+            fd = -1;
         }
         fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) fatal_error("cannot create %s", path.c_str());
@@ -491,17 +554,64 @@ struct OutFile {
             at += (uint64_t)w;
         }
     }
-    void append(const std::string& s) {
-        write_at(s.data(), s.size(), end);
-        end += s.size();
+    void append(const char* p, size_t n) {
+        write_at(p, n, end);
+        end += n;
+    }
+    void append(const std::string& s) { append(s.data(), s.size()); }
+    void drop_mapping() {
+        if (!map) return;
+        if (pinned) (void)spx_host_unregister(map);
+        ::munmap(map, map_size);
+        map = nullptr;
+        map_size = 0;
+        pinned = false;
+    }
+    // the file ends where its last complete super-batch does (the prepared tail was an estimate; after a fatal read the
+    // device may already have written later super-batches behind it)
+    void settle(bool run_is_over) {
+        if (fd < 0 || !map) return;
+        if (run_is_over && pinned) {  // (on a fatal exit other threads may still be looking: nothing is touched but the file)
+            (void)spx_host_unregister(map);
+            pinned = false;
+        }
+        if (::ftruncate(fd, (off_t)end) != 0) std::fprintf(stderr, "[spumoni-gpu] could not cut the output file to its size\n");
+        // (the mapping itself is left to the end of the process: unmapping 2 GB is 75 ms that no one waits for there)
     }
     ~OutFile() {
         if (fd >= 0) ::close(fd);
     }
 };
 
-struct Outputs {
-    OutFile lengths, pointers, docs, report;
+enum { F_LENGTHS = 0, F_POINTERS = 1, F_DOCS = 2, F_REPORT = 3, NFILES = 4 };
+}  // namespace
+struct OutputFiles {
+    OutFile f[NFILES];  // .pseudo_lengths | .lengths, .pointers, .doc_numbers, .report
+    double prepare_s = 0;
+};
+namespace {
+using Outputs = OutputFiles;
+
+// Super-batches take their place in the output files in input order: reserve() blocks until every earlier super-batch
+// has its place, then hands out this one's offsets.  (The device workers take super-batches strictly in input order, so the
+// one that is waited for is always in some worker's hands.)
+class OffsetOrder {
+public:
+    void reserve(uint64_t seq, Outputs& out, const uint64_t bytes[NFILES], uint64_t off[NFILES]) {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return next_ == seq; });
+        for (int f = 0; f < NFILES; ++f) {
+            off[f] = out.f[f].reserved;
+            out.f[f].reserved += bytes[f];
+        }
+        next_++;
+        cv_.notify_all();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    uint64_t next_ = 0;
 };
 
 // Formats reads [lo, hi) of a super-batch into text; run by several host threads at once
@@ -511,14 +621,45 @@ struct TextChunk {
     std::string report;
 };
 
+// "%-26.3g" of sum / nbins the way the reference's stream prints it (setw(26) << left, precision 3, default float
+// format): the common case -- an average that is a whole number below 1000, e.g. every read of up to one bin -- needs
+// no printf (4 * 10^6 snprintf("%.3g") calls were 0.1 s of sixteen cores); everything else goes through it.
+static inline int format_avg(char* p, uint64_t sum, size_t nbins) {
+    if (nbins != 0 && sum % nbins == 0 && sum / nbins < 1000) {
+        uint32_t v = (uint32_t)(sum / nbins);
+        int k = 0;
+        if (v >= 100) p[k++] = (char)('0' + v / 100);
+        if (v >= 10) p[k++] = (char)('0' + (v / 10) % 10);
+        p[k++] = (char)('0' + v % 10);
+        while (k < 26) p[k++] = ' ';
+        return k;
+    }
+    return std::snprintf(p, 64, "%-26.3g", (sum + 0.0) / nbins);
+}
+static inline int format_count12(char* p, size_t v) {  // "%-12zu"
+    char tmp[24];
+    int q = 24;
+    do {
+        tmp[--q] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    int k = 24 - q;
+    std::memcpy(p, tmp + q, (size_t)k);
+    while (k < 12) p[k++] = ' ';
+    return k;
+}
+
+// report_to: where the report lines of [lo, hi) go when their place in the report file is memory (every line is
+// max(30, id) + 66 bytes, so the place is known before the line is); null: collected in out.report
 void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res, size_t lo, size_t hi,
-                  TextChunk& out) {
+                  TextChunk& out, char* report_to = nullptr) {
     out.report.clear();
     out.tl.clear();
     out.tp.clear();
     out.td.clear();
+    const bool values = o.use_doc || !o.report_only || o.ms;
     for (size_t q = lo; q < hi; ++q) {
-        const uint64_t a = res.beg[q], b = res.end[q];
+        const uint64_t a = values ? res.beg[q] : 0, b = values ? res.end[q] : 0;
         if (o.use_doc) {  // compute_ms_pml.cpp:1003-1007
             out.td.header(sb.ids[q]);
             if (res.narrow)
@@ -542,166 +683,44 @@ void format_range(const RunOptions& o, const SuperBatch& sb, const Results& res,
             const size_t nbins = (size_t)c.bins_above + c.bins_below;
             const bool read_found = (c.bins_above / (c.bins_above + c.bins_below + 0.0) > 0.50);
             // setw(30) << left << id << setw(15) << status << setw(26) << avg (precision 3, default float format
-            // = %.3g) << setw(12) << above << setw(12) << below: the same bytes through snprintf (an ostringstream
-            // per thread spent 0.25 s on 4*10^6 such lines)
+            // = %.3g) << setw(12) << above << setw(12) << below: the same bytes without a stream (an ostringstream
+            // per thread spent 0.25 s on 4*10^6 such lines, snprintf 0.1 s)
             const std::string_view id = sb.ids[q];
-            char line[160];
-            const int k = std::snprintf(line, sizeof line, "%-15s%-26.3g%-12zu%-12zu\n", read_found ? "FOUND" : "NOT_PRESENT",
-                                        (c.sum_max_bin_values + 0.0) / nbins, (size_t)c.bins_above, (size_t)c.bins_below);
-            out.report.append(id.data(), id.size());
-            if (id.size() < 30) out.report.append(30 - id.size(), ' ');
-            out.report.append(line, (size_t)k);
-        }
-    }
-}
-
-double g_format_s = 0;  // formatting alone, thread 0's share of every super-batch (for [timing])
-
-// The text came from the device (spx_text.hip).  Two stages, so that the one thing that cannot be done in parallel --
-// writes to one file serialise on its inode lock: 2 GB go into tmpfs at 5.7 GB/s however many threads call pwrite -- is
-// never waited for by anything else:
-//   begin   helper threads drop the ">id\n" lines into their gaps, then go on to format the report lines of their
-//           ranges; the calling (writer) thread waits for the headers only and writes each stream with ONE pwrite;
-//   finish  (the report thread, one super-batch behind) joins the helpers and appends the report lines.
-struct TextJob {
-    RunOptions ro;
-    size_t nt = 0, nreads = 0;
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t filled = 0;
-    std::vector<std::thread> th;
-    std::vector<TextChunk> chunks;
-};
-
-void write_results_text_begin(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res, TextJob& job) {
-    const size_t nreads = sb.nreads();
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
-    job.nt = nt;
-    job.nreads = nreads;
-    job.filled = 0;
-    if (job.chunks.size() < nt) job.chunks.resize(nt);
-    job.ro = o;  // only the report is left to format
-    job.ro.use_doc = false;
-    job.ro.ms = false;
-    job.ro.report_only = true;
-    OutFile* const files[3] = {&out.lengths, &out.pointers, &out.docs};
-    bool open_[3];
-    for (int i = 0; i < 3; ++i) open_[i] = (res.streams & (1u << i)) && files[i]->is_open();
-    const SuperBatch* psb = &sb;
-    const Results* pres = &res;
-    TextJob* pj = &job;
-    const bool o0 = open_[0], o1 = open_[1], o2 = open_[2];
-    auto helper = [psb, pres, pj, o0, o1, o2](size_t t) {
-        const size_t lo = pj->nreads * t / pj->nt, hi = pj->nreads * (t + 1) / pj->nt;
-        const bool op[3] = {o0, o1, o2};
-        for (int i = 0; i < 3; ++i) {
-            if (!op[i]) continue;
-            char* base = const_cast<char*>(pres->text[i].data());
-            const uint64_t* ls = pres->line_start[i].data();
-            for (size_t q = lo; q < hi; ++q) {
-                char* p = base + ls[q];
-                const std::string_view id = psb->ids[q];
-                *p++ = '>';
-                std::memcpy(p, id.data(), id.size());
-                p[id.size()] = '\n';
-            }
-        }
-        {
-            std::lock_guard<std::mutex> g(pj->mu);
-            if (++pj->filled == pj->nt) pj->cv.notify_all();
-        }
-        format_range(pj->ro, *psb, *pres, lo, hi, pj->chunks[t]);
-    };
-    job.th.clear();
-    for (size_t t = 0; t < nt; ++t) job.th.emplace_back(helper, t);
-    const auto tf0 = std::chrono::steady_clock::now();
-    {
-        std::unique_lock<std::mutex> g(job.mu);
-        job.cv.wait(g, [&] { return job.filled == nt; });
-    }
-    for (int i = 0; i < 3; ++i) {
-        if (!open_[i]) continue;
-        const uint64_t bytes = res.line_start[i][nreads];
-        files[i]->write_at(res.text[i].data(), bytes, files[i]->end);
-        files[i]->end += bytes;
-    }
-    g_format_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
-}
-
-void write_results_text_finish(Outputs& out, const RunOptions& o, TextJob& job) {
-    for (auto& x : job.th) x.join();
-    job.th.clear();
-    if (o.write_report)
-        for (size_t t = 0; t < job.nt; ++t) {
-            const std::string& r = job.chunks[t].report;
-            if (r.empty()) continue;
-            out.report.write_at(r.data(), r.size(), out.report.end);
-            out.report.end += r.size();
-        }
-}
-
-void write_results(Outputs& out, const RunOptions& o, const SuperBatch& sb, const Results& res,
-                   std::vector<TextChunk>& chunks) {
-    if (res.device_text) {  // (callers without a report stage: both stages at once)
-        TextJob job;
-        write_results_text_begin(out, o, sb, res, job);
-        write_results_text_finish(out, o, job);
-        return;
-    }
-    const size_t nreads = sb.nreads();
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (nreads + 4095) / 4096));
-    if (chunks.size() < nt) chunks.resize(nt);
-    // where thread t's text goes in each file: known once every thread has formatted its part
-    std::vector<uint64_t> at_l(nt + 1), at_p(nt + 1), at_d(nt + 1), at_r(nt + 1);
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t formatted = 0;
-    bool placed = false;
-    auto lo_of = [&](size_t t) { return nreads * t / nt; };
-    auto work = [&](size_t t) {
-        TextChunk& c = chunks[t];
-        const auto tf0 = std::chrono::steady_clock::now();
-        format_range(o, sb, res, lo_of(t), lo_of(t + 1), c);
-        if (t == 0) g_format_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
-        {
-            std::unique_lock<std::mutex> g(mu);
-            if (++formatted == nt) {  // the last one to finish lays the chunks out, in input order
-                at_l[0] = out.lengths.end;
-                at_p[0] = out.pointers.end;
-                at_d[0] = out.docs.end;
-                at_r[0] = out.report.end;
-                for (size_t i = 0; i < nt; ++i) {
-                    at_l[i + 1] = at_l[i] + chunks[i].tl.len;
-                    at_p[i + 1] = at_p[i] + chunks[i].tp.len;
-                    at_d[i + 1] = at_d[i] + chunks[i].td.len;
-                    at_r[i + 1] = at_r[i] + chunks[i].report.size();
-                }
-                placed = true;
-                cv.notify_all();
+            char line[192];
+            int k = 0;
+            if (read_found) {
+                std::memcpy(line, "FOUND          ", 15);
             } else {
-                cv.wait(g, [&] { return placed; });
+                std::memcpy(line, "NOT_PRESENT    ", 15);
+            }
+            k = 15;
+            k += format_avg(line + k, c.sum_max_bin_values, nbins);
+            k += format_count12(line + k, (size_t)c.bins_above);
+            k += format_count12(line + k, (size_t)c.bins_below);
+            line[k++] = '\n';
+            if (report_to) {
+                std::memcpy(report_to, id.data(), id.size());
+                report_to += id.size();
+                if (id.size() < 30) {
+                    std::memset(report_to, ' ', 30 - id.size());
+                    report_to += 30 - id.size();
+                }
+                std::memcpy(report_to, line, (size_t)k);
+                report_to += k;
+            } else {
+                out.report.append(id.data(), id.size());
+                if (id.size() < 30) out.report.append(30 - id.size(), ' ');
+                out.report.append(line, (size_t)k);
             }
         }
-        if (c.tl.len) out.lengths.write_at(c.tl.buf.data(), c.tl.len, at_l[t]);
-        if (o.ms && c.tp.len) out.pointers.write_at(c.tp.buf.data(), c.tp.len, at_p[t]);
-        if (o.use_doc && c.td.len) out.docs.write_at(c.td.buf.data(), c.td.len, at_d[t]);
-        if (o.write_report && !c.report.empty()) out.report.write_at(c.report.data(), c.report.size(), at_r[t]);
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-    out.lengths.end = at_l[nt];
-    out.pointers.end = at_p[nt];
-    out.docs.end = at_d[nt];
-    out.report.end = at_r[nt];
+    }
 }
 
 size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
-    out.lengths.open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
-    if (o.ms) out.pointers.open(o.pattern_file + ".pointers");
-    if (o.use_doc) out.docs.open(o.pattern_file + ".doc_numbers");
-    if (o.write_report) out.report.open(o.pattern_file + ".report");
+    out.f[F_LENGTHS].open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
+    if (o.ms) out.f[F_POINTERS].open(o.pattern_file + ".pointers");
+    if (o.use_doc) out.f[F_DOCS].open(o.pattern_file + ".doc_numbers");
+    if (o.write_report) out.f[F_REPORT].open(o.pattern_file + ".report");
     double percentile = 0.0;
     std::string err;
     // the reference does not check the stream either (:867-869): a missing null database
@@ -715,28 +734,207 @@ size_t open_outputs_and_threshold(Outputs& out, const RunOptions& o) {
            << std::setw(19) << std::left << "avg max-value (thr=" << std::setw(2) << std::left
            << max_value_thr << std::setw(5) << std::left << "):" << std::setw(12) << std::left
            << "above thr:" << std::setw(12) << std::left << "below thr:" << std::endl;
-        out.report.append(hd.str());
+        out.f[F_REPORT].append(hd.str());
     }
     return max_value_thr;
+}
+
+// ---- a persistent pool -----------------------------------------------------------------------------------------------------
+// Round 4 created and joined its helper threads per phase and super-batch (parse, assemble, headers, report: some
+// 800 thread starts in a 0.4 s run) and ran one super-batch's phases strictly one after the other.  The pool's threads
+// live as long as the run; run(n, f) hands f(0) .. f(n - 1) to them AND to the caller, returns when all are done, and may
+// be called from several threads at once (the feeders and the device workers): their items simply share the threads.
+class Pool {
+public:
+    explicit Pool(size_t threads) {
+        for (size_t t = 0; t < threads; ++t) th_.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    size_t size() const { return th_.size() + 1; }
+    template <class F>
+    void run(size_t n, F&& f) {
+        if (n == 0) return;
+        if (n == 1 || th_.empty()) {
+            for (size_t i = 0; i < n; ++i) f(i);
+            return;
+        }
+        auto job = std::make_shared<Job>();
+        job->n = n;
+        job->f = [&f](size_t i) { f(i); };
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            jobs_.push_back(job);
+        }
+        cv_.notify_all();
+        work(*job);
+        std::unique_lock<std::mutex> g(job->mu);
+        job->cv.wait(g, [&] { return job->done == job->n; });
+    }
+
+private:
+    struct Job {
+        std::function<void(size_t)> f;
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t done = 0;
+    };
+    static void work(Job& j) {
+        size_t mine = 0;
+        for (;;) {
+            const size_t i = j.next.fetch_add(1);
+            if (i >= j.n) break;
+            j.f(i);
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> g(j.mu);
+            j.done += mine;
+            if (j.done == j.n) j.cv.notify_all();
+        }
+    }
+    void worker() {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                for (;;) {
+                    while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->n) jobs_.pop_front();
+                    if (stop_ || !jobs_.empty()) break;
+                    cv_.wait(g);
+                }
+                if (jobs_.empty()) return;  // (stop_)
+                j = jobs_.front();
+            }
+            work(*j);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> jobs_;
+    bool stop_ = false;
+    std::vector<std::thread> th_;
+};
+
+struct Piece {
+    const char* p;
+    size_t n;
+};
+
+// bytes of a read's report line (compute_ms_pml.cpp:1012-1020: setw(30) id, setw(15) status, setw(26) average, two
+// setw(12) counts, endl): known from the id alone, which is what lets the lines be formatted at their place in the file
+static inline uint64_t report_line_bytes(size_t id_len) { return std::max<size_t>(30, id_len) + 66; }
+
+// After the device: what every output file gets from this super-batch.  Text from the device (spx_text.hip): the ">id\n"
+// lines are dropped into their gaps and the report lines formatted, by the pool -- in the file itself where the text
+// landed there, in the slot's buffers otherwise (a piece for the file's writer thread); values from the device
+// (SPUMONI_HOST_FORMAT, report-only PML): everything is formatted here.  file_off: the super-batch's place in every file
+// (device-text runs).
+void finish_batch(Pool& pool, const RunOptions& o, Outputs& out, const SuperBatch& sb, const Results& res,
+                  std::vector<TextChunk>& chunks, const uint64_t file_off[NFILES], std::vector<Piece> pieces[NFILES]) {
+    for (int i = 0; i < NFILES; ++i) pieces[i].clear();
+    const size_t nreads = sb.nreads();
+    if (nreads == 0) return;
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(pool.size(), (nreads + 2047) / 2048));
+    if (chunks.size() < nt) chunks.resize(nt);
+    // the report's lines go straight to their place when that is memory
+    char* report_base = nullptr;
+    std::vector<uint64_t> rep_off;
+    if (o.write_report && out.f[F_REPORT].map) {
+        rep_off.assign(nt + 1, 0);
+        pool.run(nt, [&](size_t t) {
+            uint64_t b = 0;
+            for (size_t q = nreads * t / nt; q < nreads * (t + 1) / nt; ++q) b += report_line_bytes(sb.ids[q].size());
+            rep_off[t + 1] = b;
+        });
+        for (size_t t = 0; t < nt; ++t) rep_off[t + 1] += rep_off[t];
+        if (file_off[F_REPORT] + rep_off[nt] <= out.f[F_REPORT].map_size) report_base = out.f[F_REPORT].map + file_off[F_REPORT];
+    }
+    if (res.device_text) {
+        RunOptions ro = o;  // only the report is left to format
+        ro.use_doc = false;
+        ro.ms = false;
+        ro.report_only = true;
+        bool open_[3], direct[3];
+        char* dest[3] = {nullptr, nullptr, nullptr};  // the stream's place in its file, when that is memory
+        for (int i = 0; i < 3; ++i) {
+            open_[i] = (res.streams & (1u << i)) && out.f[i].is_open();
+            const uint64_t bytes = open_[i] ? res.line_start[i][nreads] : 0;
+            const bool fits = open_[i] && out.f[i].map && file_off[i] + bytes <= out.f[i].map_size;
+            dest[i] = fits ? out.f[i].map + file_off[i] : nullptr;
+            direct[i] = fits && res.text_at[i] == dest[i];  // the device wrote it there
+        }
+        pool.run(nt, [&](size_t t) {
+            const size_t lo = nreads * t / nt, hi = nreads * (t + 1) / nt;
+            for (int i = 0; i < 3; ++i) {
+                if (!open_[i]) continue;
+                const uint64_t* ls = res.line_start[i].data();
+                char* base = res.text_at[i];
+                if (dest[i] && !direct[i]) {
+                    // mapped but not page-locked for the device (or the place was not known in time): this part's lines
+                    // are copied into the file here -- the parts are whole lines, so nobody waits for anybody
+                    std::memcpy(dest[i] + ls[lo], base + ls[lo], (size_t)(ls[hi] - ls[lo]));
+                    base = dest[i];
+                }
+                for (size_t q = lo; q < hi; ++q) {
+                    char* p = base + ls[q];
+                    const std::string_view id = sb.ids[q];
+                    *p++ = '>';
+                    std::memcpy(p, id.data(), id.size());
+                    p[id.size()] = '\n';
+                }
+            }
+            format_range(ro, sb, res, lo, hi, chunks[t], report_base ? report_base + rep_off[t] : nullptr);
+        });
+        for (int i = 0; i < 3; ++i)
+            if (open_[i] && !dest[i]) pieces[i].push_back(Piece{res.text_at[i], (size_t)res.line_start[i][nreads]});
+    } else {
+        pool.run(nt, [&](size_t t) {
+            format_range(o, sb, res, nreads * t / nt, nreads * (t + 1) / nt, chunks[t], report_base ? report_base + rep_off[t] : nullptr);
+        });
+        for (size_t t = 0; t < nt; ++t) {
+            const TextChunk& c = chunks[t];
+            if (c.tl.len) pieces[F_LENGTHS].push_back(Piece{c.tl.buf.data(), c.tl.len});
+            if (o.ms && c.tp.len) pieces[F_POINTERS].push_back(Piece{c.tp.buf.data(), c.tp.len});
+            if (o.use_doc && c.td.len) pieces[F_DOCS].push_back(Piece{c.td.buf.data(), c.td.len});
+        }
+    }
+    if (o.write_report && !report_base)
+        for (size_t t = 0; t < nt; ++t)
+            if (!chunks[t].report.empty()) pieces[F_REPORT].push_back(Piece{chunks[t].report.data(), chunks[t].report.size()});
 }
 
 }  // namespace
 
 namespace {
 
-// A super-batch in flight plus what has to happen after it was written.
+// A super-batch in flight.
 struct Slot {
     SuperBatch sb;
     Results res;
     uint64_t seq = 0;            // position of this super-batch in the input (results are written in this order)
     bool last = false;           // no more input after this one
-    std::vector<std::vector<ParsedRead>> parsed;  // fill_slot's per-thread reads (kept: their capacity is reused)
-    std::unique_ptr<TextJob> job;  // device text: the helpers of the write in flight (finished by the report thread)
+    std::vector<std::vector<ReadRec>> recs;  // the feeder's reads, per part (kept: their capacity is reused)
+    std::vector<TextChunk> chunks;           // per part: the report lines (host-formatted: the values lines too)
+    std::vector<Piece> pieces[NFILES];       // what each file's writer copies into the file for this super-batch
+    uint64_t file_off[NFILES] = {};          // device-text runs: the super-batch's place in every file (OffsetOrder)
+    uint64_t file_bytes[NFILES] = {};        // ... and its size there
+    bool placed = false;
+    uint64_t report_bytes = 0;               // bytes of its report lines (known from the ids)
+    std::atomic<int> writers_left{0};
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
 };
 
-// blocking hand-off of slot indices between the three stages (parse -> GPU -> write)
+// blocking hand-off of slot indices between the stages
 class SlotQueue {
 public:
     void push(int v) {
@@ -748,126 +946,19 @@ public:
         std::unique_lock<std::mutex> g(mu_);
         cv_.wait(g, [&] { return !q_.empty(); });
         int v = q_.front();
-        q_.erase(q_.begin());
+        q_.pop_front();
         return v;
     }
 
 private:
     std::mutex mu_;
     std::condition_variable cv_;
-    std::vector<int> q_;
+    std::deque<int> q_;
 };
 
-// Fills `slot` from the input: segmentation replayed sequentially (reads.cpp), the batches of
-// the super-batch parsed by several threads, reads upper-cased while they are copied into the
-// page-locked buffer.  A malformed / empty read truncates the super-batch there and is reported
-// after everything before it has been written, like the reference running read by read.
-double g_parse_s[4] = {0, 0, 0, 0};  // fill_slot: segmentation (serial), parse, placement (serial), copy
-void fill_slot(ReadFile& input, const RunOptions& o, Slot& slot, bool& input_done) {
-    auto tick = [] { return std::chrono::steady_clock::now(); };
-    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
-    auto t_phase = tick();
-    slot.sb.clear();
-    slot.last = false;
-    slot.deferred = 0;
-    std::vector<ReadFile::Range> ranges;
-    size_t bytes = 0;
-    while (!input_done && bytes < o.super_batch_chars) {
-        ReadFile::Range r;
-        if (!input.next_range(1000, r)) {  // reader.loadBatch(input_file, 1000)   (:903)
-            input_done = true;
-            break;
-        }
-        bytes += r.bytes;
-        ranges.push_back(r);
-    }
-    slot.last = input_done;
-    g_parse_s[0] += since(t_phase);
-    t_phase = tick();
-    const size_t nt = std::max<size_t>(1, std::min<size_t>(o.format_threads, (ranges.size() + 63) / 64));
-    std::vector<std::vector<ParsedRead>>& parsed = slot.parsed;
-    if (parsed.size() < nt) parsed.resize(nt);
-    for (auto& v : parsed) v.clear();
-    std::vector<ReadFile::ParseError> errs(nt);
-    std::vector<size_t> err_at(nt, 0);
-    auto work = [&](size_t t) {
-        const size_t lo = ranges.size() * t / nt, hi = ranges.size() * (t + 1) / nt;
-        for (size_t i = lo; i < hi && !errs[t].fatal; ++i) input.parse_range(ranges[i], parsed[t], errs[t]);
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-    g_parse_s[1] += since(t_phase);
-    t_phase = tick();
-    // where does every thread's part go, and where is the first problem (if any)?
-    std::vector<size_t> take(nt, 0), chars(nt, 0);
-    for (size_t t = 0; t < nt && !slot.deferred; ++t) {
-        for (const ParsedRead& rd : parsed[t]) {
-            if (rd.seq().empty()) {  // :926-931
-                slot.deferred = 2;
-                slot.deferred_msg = std::string(rd.id);
-                break;
-            }
-            take[t]++;
-            chars[t] += rd.seq().size();
-        }
-        if (!slot.deferred && errs[t].fatal) {
-            slot.deferred = 1;
-            slot.deferred_msg = errs[t].message;
-        }
-    }
-    if (slot.deferred) slot.last = true;
-    std::vector<size_t> r0(nt + 1, 0), c0(nt + 1, 0);
-    for (size_t t = 0; t < nt; ++t) {
-        r0[t + 1] = r0[t] + take[t];
-        c0[t + 1] = c0[t] + chars[t];
-    }
-    const size_t nreads = r0[nt], nchars = c0[nt];
-    slot.sb.ids.resize(nreads);
-    slot.sb.offs.resize(nreads + 1);
-    slot.sb.offs[0] = 0;
-    slot.sb.seqs.resize_uninit(nchars);
-    g_parse_s[2] += since(t_phase);
-    t_phase = tick();
-    auto assemble = [&](size_t t) {
-        size_t rdx = r0[t], cpos = c0[t];
-        for (size_t q = 0; q < take[t]; ++q) {
-            ParsedRead& rd = parsed[t][q];
-            uint8_t* dst = slot.sb.seqs.data() + cpos;
-            const char* src = rd.seq().data();
-            const size_t len = rd.seq().size();
-            // make sure all characters are upper-case (:916-917; ::toupper in the "C" locale)
-            for (size_t i = 0; i < len; ++i) {
-                const unsigned char ch = (unsigned char)src[i];
-                dst[i] = (uint8_t)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
-            }
-            cpos += len;
-            slot.sb.offs[rdx + 1] = cpos;
-            slot.sb.ids[rdx] = rd.id;
-            rdx++;
-        }
-    };
-    th.clear();
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(assemble, t);
-    assemble(0);
-    for (auto& x : th) x.join();
-    g_parse_s[3] += since(t_phase);
-}
-
-}  // namespace
-
-namespace {
-struct StageTimer {  // per-stage wall time on stderr (ours)
-    const char* name;
-    double total = 0;
-    std::chrono::steady_clock::time_point t0;
-    void start() { t0 = std::chrono::steady_clock::now(); }
-    void stop() { total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-};
-}  // namespace
-
-// Re-sequences the super-batches the device workers finish, in whatever order, into input order.
+// Re-sequences the super-batches the device workers finish, in whatever order, into input order -- for several readers
+// (one writer thread per output file): look() blocks until super-batch `seq` is done and leaves the entry where it is,
+// drop() takes it out once every writer is through with it.
 class OrderedDone {
 public:
     void put(uint64_t seq, int slot) {
@@ -875,28 +966,121 @@ public:
         done_.emplace_back(seq, slot);
         cv_.notify_all();
     }
-    int take(uint64_t seq) {  // blocks until super-batch `seq` is done
+    int look(uint64_t seq) {
         std::unique_lock<std::mutex> g(mu_);
         for (;;) {
-            for (size_t i = 0; i < done_.size(); ++i)
-                if (done_[i].first == seq) {
-                    const int slot = done_[i].second;
-                    done_.erase(done_.begin() + (long)i);
-                    return slot;
-                }
+            if (seq > last_) return -1;
+            for (const auto& e : done_)
+                if (e.first == seq) return e.second;
             cv_.wait(g);
         }
+    }
+    void set_last(uint64_t seq) {  // nothing after super-batch `seq`: look() for a later one returns -1
+        std::lock_guard<std::mutex> g(mu_);
+        last_ = std::min(last_, seq);
+        cv_.notify_all();
+    }
+    void drop(uint64_t seq) {
+        std::lock_guard<std::mutex> g(mu_);
+        for (size_t i = 0; i < done_.size(); ++i)
+            if (done_[i].first == seq) {
+                done_.erase(done_.begin() + (long)i);
+                return;
+            }
     }
 
 private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<std::pair<uint64_t, int>> done_;
+    uint64_t last_ = ~0ull;
 };
 
+// Fills `slot` from the ranges of one super-batch (the reference's ~1000-base batches, cut sequentially by the caller):
+// the pool scans them into reads (positions in the mapped file), every part counts its own reads and characters -- no
+// serial pass over the reads --, and the same parts then copy the reads, upper-cased, into the page-locked buffer and
+// fill in ids, offsets and header sizes.  A malformed / empty read truncates the super-batch there and is reported after
+// everything before it has been written, like the reference running read by read.
+void fill_slot(Pool& pool, const ReadFile& input, const std::vector<ReadFile::Range>& ranges, Slot& slot, double t_phase[2]) {
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    auto t0 = tick();
+    slot.sb.clear();
+    slot.deferred = 0;
+    slot.placed = false;
+    slot.report_bytes = 0;
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(pool.size(), (ranges.size() + 63) / 64));
+    if (slot.recs.size() < nt) slot.recs.resize(nt);
+    struct Part {
+        size_t take = 0, chars = 0, longest = 0, report = 0;
+        int problem = 0;  // 2: read `take` is empty; 1: a malformed record follows the part's reads
+        ReadFile::ParseError err;
+    };
+    std::vector<Part> part(nt);
+    pool.run(nt, [&](size_t t) {
+        std::vector<ReadRec>& v = slot.recs[t];
+        v.clear();
+        Part& pt = part[t];
+        const size_t lo = ranges.size() * t / nt, hi = ranges.size() * (t + 1) / nt;
+        for (size_t i = lo; i < hi && !pt.err.fatal; ++i) input.scan_range(ranges[i], v, pt.err);
+        for (const ReadRec& rd : v) {
+            if (rd.seq_len == 0) {  // :926-931
+                pt.problem = 2;
+                break;
+            }
+            pt.take++;
+            pt.chars += rd.seq_len;
+            pt.longest = std::max<size_t>(pt.longest, rd.seq_len);
+            pt.report += report_line_bytes(rd.id_len);
+        }
+        if (!pt.problem && pt.err.fatal) pt.problem = 1;
+    });
+    // where does every part's share go, and where is the first problem (if any)?
+    std::vector<size_t> r0(nt + 1, 0), c0(nt + 1, 0);
+    for (size_t t = 0; t < nt; ++t) {
+        if (slot.deferred) part[t].take = part[t].chars = part[t].longest = part[t].report = 0;  // (behind the problem: not part of the run)
+        slot.report_bytes += part[t].report;
+        r0[t + 1] = r0[t] + part[t].take;
+        c0[t + 1] = c0[t] + part[t].chars;
+        slot.sb.longest = std::max<uint64_t>(slot.sb.longest, part[t].longest);
+        if (!slot.deferred && part[t].problem) {
+            slot.deferred = part[t].problem;
+            slot.deferred_msg = part[t].problem == 2 ? std::string(slot.recs[t][part[t].take].id, slot.recs[t][part[t].take].id_len)
+                                                     : part[t].err.message;
+        }
+    }
+    if (slot.deferred) slot.last = true;
+    const size_t nreads = r0[nt], nchars = c0[nt];
+    slot.sb.ids.resize(nreads);
+    slot.sb.offs.resize_uninit(nreads + 1);
+    slot.sb.offs[0] = 0;
+    slot.sb.gap.resize_uninit(nreads);
+    slot.sb.seqs.resize_uninit(nchars);
+    t_phase[0] += since(t0);
+    t0 = tick();
+    pool.run(nt, [&](size_t t) {
+        size_t rdx = r0[t], cpos = c0[t];
+        const std::vector<ReadRec>& v = slot.recs[t];
+        for (size_t q = 0; q < part[t].take; ++q) {
+            const ReadRec& rd = v[q];
+            input.copy_seq_upper(rd, slot.sb.seqs.data() + cpos);  // all characters upper-case (:916-917)
+            cpos += rd.seq_len;
+            slot.sb.offs[rdx + 1] = cpos;
+            slot.sb.ids[rdx] = std::string_view(rd.id, rd.id_len);
+            slot.sb.gap[rdx] = rd.id_len + 2;
+            rdx++;
+        }
+    });
+    t_phase[1] += since(t0);
+}
+
+}  // namespace
+
 // Called on a helper thread while the index loads: the page-locked blocks the slots of classify_reads will ask for
-// (per slot: the reads of a super-batch, and per output stream its text and its record offsets).
-void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
+// (per slot: the reads of a super-batch with their offsets and header sizes, the class records, and per output stream
+// its text and its record offsets).
+static size_t slots_for(size_t nworkers) { return nworkers + 4; }  // one per worker, two being parsed, two being written
+void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
     if (spx_device_count() <= 0) return;
     // sized from the reads file, not from the super-batch limit alone: a small file needs small blocks and few
     // slots, and below a megabyte locking pages ahead of time buys nothing
@@ -904,14 +1088,17 @@ void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
     if (::stat(o.pattern_file.c_str(), &sb) != 0 || sb.st_size < (1 << 20)) return;
     const size_t fsize = (size_t)sb.st_size;
     const size_t batches = fsize / std::max<size_t>(o.super_batch_chars, 1) + 1;
-    const size_t nslots = std::min<size_t>(2 * std::max<size_t>(ndev, 1) + 3, batches + 1);
+    const size_t nslots = std::min<size_t>(slots_for(std::max<size_t>(nworkers, 1)), batches + 1);
     const bool report_only = o.report_only && !o.ms && o.write_report;
     const size_t chars = std::min<size_t>(o.super_batch_chars, fsize) + std::min<size_t>(4u << 20, fsize / 8 + 4096);
     std::vector<size_t> sizes;
     for (size_t i = 0; i < nslots; ++i) {
-        sizes.push_back(chars);  // reads
-        if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
         const size_t reads_guess = chars / 100 + 4096;
+        sizes.push_back(chars);  // reads
+        sizes.push_back((reads_guess + 1) * 8);  // their offsets
+        sizes.push_back(reads_guess * 4);        // their header sizes
+        if (o.write_report) sizes.push_back(reads_guess * sizeof(spx_class));
+        if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
         if (!report_only) {  // lengths: "<value> " is 2-4 bytes for most values
             sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
             sizes.push_back((reads_guess + 1) * 8);
@@ -932,12 +1119,128 @@ void prepare_pinned_pool(const RunOptions& o, size_t ndev) {
     }
 }
 
-size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
-    Outputs out;
+// ---- the output files' tails as memory, prepared while the index loads ----------------------------------------------------
+namespace {
+OutputFiles* g_live_outputs = nullptr;  // what a fatal exit has to settle (reads.cpp: leave -> the exit hook)
+std::mutex g_settle_mu;
+// A fatal read ends the run while the other threads -- the device's copies, the pool -- may still be writing later
+// super-batches into the files' mapped tails: cutting the files to their logical ends turns those stores into SIGBUS.  The
+// process is on its way out; a thread that gets there simply stays there.
+extern "C" void park_on_sigbus(int) {
+    for (;;) ::pause();
+}
+void settle_outputs(bool run_is_over) {
+    std::lock_guard<std::mutex> g(g_settle_mu);
+    if (!g_live_outputs) return;
+    {
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = park_on_sigbus;
+        sigemptyset(&sa.sa_mask);
+        (void)::sigaction(SIGBUS, &sa, nullptr);
+    }
+    for (OutFile& f : g_live_outputs->f) f.settle(run_is_over);
+    g_live_outputs = nullptr;
+}
+void settle_outputs_at_exit() { settle_outputs(false); }
+bool env_is(const char* name, const char* value) {
+    const char* e = std::getenv(name);
+    return e && std::strcmp(e, value) == 0;
+}
+}  // namespace
+
+OutputFiles* prepare_outputs(const RunOptions& o, uint64_t reads_file_bytes, uint64_t reads_guess) {
+    OutputFiles* out = new OutputFiles;
+    // only the path that produces the files' text on the device lands it in the files (SPUMONI_MAP_OUTPUT=0: never)
+    if (o.is_general_text || std::getenv("SPUMONI_HOST_FORMAT") || env_is("SPUMONI_MAP_OUTPUT", "0")) return out;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool digest = o.use_promotions || o.use_dna_letters;
+    // values per input character: every character without digestion; with it about two minimizers per window of
+    // w - k + 1 k-mers (k letters each with -a)
+    double v = 1.0;
+    if (digest) v = std::min(1.0, 2.2 / (double)(o.w - o.k + 2) * (o.use_dna_letters ? (double)o.k : 1.0));
+    double factor = 1.0;
+    if (const char* e = std::getenv("SPUMONI_MAP_FACTOR")) factor = std::max(0.0, std::atof(e));
+    const double fb = (double)reads_file_bytes;
+    // bytes per value: lengths "<1-3 digits> ", pointers "<up to 13 digits> ", document ids "<1-3 digits> "; + the ">id" lines
+    uint64_t est[NFILES] = {0, 0, 0, 0};
+    const bool report_only = o.report_only && !o.ms && o.write_report;
+    if (!report_only) est[F_LENGTHS] = (uint64_t)(fb * (0.2 + (o.ms ? 3.6 : 2.8) * v) * factor);
+    if (o.ms) est[F_POINTERS] = (uint64_t)(fb * (0.2 + 11.0 * v) * factor);
+    if (o.use_doc) est[F_DOCS] = (uint64_t)(fb * (0.2 + 2.3 * v) * factor);
+    if (o.write_report) est[F_REPORT] = (uint64_t)((double)(reads_guess + 16) * 100.0 * factor) + 256;
+    // (never more than a third of what the machine has free: the estimate is an upper-ish bound, not a promise)
+    uint64_t avail = ~0ull;
+    {
+        std::ifstream mi("/proc/meminfo");
+        std::string key;
+        uint64_t kb;
+        std::string unit;
+        while (mi >> key >> kb >> unit)
+            if (key == "MemAvailable:") avail = kb * 1024;
+    }
+    uint64_t want = 0;
+    for (uint64_t e : est) want += e;
+    if (want > avail / 3) return out;
+    static const char* const ext[NFILES] = {nullptr, ".pointers", ".doc_numbers", ".report"};
+    // (SPUMONI_MAP_MIN / SPUMONI_MAP_FACTOR: tests map the tails of tiny files, and size them short so that a run crosses from
+    // the prepared tail into plain writes)
+    uint64_t map_min = 8u << 20;
+    if (const char* e = std::getenv("SPUMONI_MAP_MIN")) map_min = std::strtoull(e, nullptr, 10);
+    for (int f = 0; f < NFILES; ++f) {
+        if (est[f] == 0) continue;
+        if (est[f] < map_min) continue;  // (small files: write() is fine)
+        OutFile& of = out->f[f];
+        const std::string final_path = o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]);
+        of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
+        const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) continue;
+        register_leftover(of.temp_path);
+        const uint64_t size = (est[f] + 4095) & ~4095ull;
+        void* m = MAP_FAILED;
+        if (::fallocate(fd, 0, 0, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) {  // (a file system that cannot do either: the file is written the ordinary way)
+            if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
+            of.fd = fd;
+            continue;
+        }
+        // the page table entries now, by a few threads, so that nothing faults inside the run
+        {
+            const unsigned nt = 4;
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([=] {
+                    const uint64_t lo = (size / 4096 * t / nt) * 4096, hi = t + 1 == nt ? size : (size / 4096 * (t + 1) / nt) * 4096;
+#ifdef MADV_POPULATE_WRITE
+                    if (hi > lo && ::madvise((char*)m + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+                    for (uint64_t a = lo; a < hi; a += 4096) {
+                        volatile char* p = (volatile char*)m + a;
+                        *p = *p;
+                    }
+                });
+            for (auto& x : th) x.join();
+        }
+        of.fd = fd;
+        of.map = (char*)m;
+        of.map_size = size;
+        // the report is written by the host's threads; the value streams by the device
+        if (f != F_REPORT && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) of.pinned = spx_host_register(m, size) == SPX_OK;
+    }
+    out->prepare_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return out;
+}
+
+size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, OutputFiles* prepared) {
+    Outputs& out = prepared ? *prepared : *new OutputFiles;
     const size_t max_value_thr = open_outputs_and_threshold(out, o);
-    StageTimer t_load{"load+index lines", 0, {}}, t_parse{"segment+parse", 0, {}}, t_write{"format+write", 0, {}},
-        t_report{"report (one behind)", 0, {}};
-    t_load.start();
+    {
+        std::lock_guard<std::mutex> g(g_settle_mu);
+        g_live_outputs = &out;
+    }
+    set_exit_hook(&settle_outputs_at_exit);
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     // the reads file is mapped and its lines are found while the index loads (spumoni_main.cpp)
     std::unique_ptr<ReadFile> own_input;
     if (!preloaded) {
@@ -945,33 +1248,76 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
         preloaded = own_input.get();
     }
     ReadFile& input = *preloaded;
-    t_load.stop();
-    // Parser -> ONE queue of parsed super-batches -> one worker thread per device -> ordered writer.
-    // Every device pulls its next super-batch when it is free (reads are independent,
-    // compute_ms_pml.cpp:907-938: nothing is carried from one read to the next), so a slower or busier
-    // device simply takes fewer of them; the writer puts the results back into input order (the
-    // reference's -t 1 order).  Slots: one being parsed, one per device, one being written, and one
-    // more per device so that no device waits for the parser.
-    const size_t ndev = set.ix.size();
-    const int NSLOTS = (int)(2 * ndev + 3);  // (one more: the report thread holds a slot too)
-    // (the slots outlive the call on purpose: unlocking their ~1 GB of page-locked buffers takes a few tenths of a
+    // Segmentation (sequential: it defines which reads exist) -> feeders, each parsing a super-batch on the pool -> the
+    // device workers, which take the parsed super-batches in input order (SPUMONI_GPUS: one worker per entry; two that name
+    // the same device are two query contexts over one copy of the index, so that one's copies run under the other's
+    // kernels): [digestion +] walk + text on the device, the super-batch's place in every output file reserved (in input
+    // order) as soon as its sizes are known, the text copied by the device into the files' pages, headers and report
+    // lines written there by the pool -> one writer thread per output FILE for whatever did not go straight into the file,
+    // in input order (the reference's -t 1 order); the last one through with a super-batch makes it final.  Reads are
+    // independent (compute_ms_pml.cpp:907-938: nothing is carried from one read to the next), so a slower or busier
+    // device simply takes fewer super-batches.  The reference's loop this replaces: compute_ms_pml.cpp:890-1024.
+    const size_t nworkers = set.ix.size();
+    constexpr int NFEED = 2;
+    const int NSLOTS = (int)slots_for(nworkers);
+    Pool pool(std::max<size_t>(1, o.format_threads) - 1);
+    // (the slots outlive the call on purpose: unlocking their page-locked buffers takes a few tenths of a
     // second that the run would spend after its last byte is written; the process ends right after and the
     // operating system takes the pages back)
     std::vector<Slot>& slots = *new std::vector<Slot>((size_t)NSLOTS);
-    const auto t_stage0 = std::chrono::steady_clock::now();
-    SlotQueue free_q, parsed_q;
-    OrderedDone done;
+    const auto t_stage0 = tick();
+    SlotQueue free_q;
+    OrderedDone parsed, done;
+    OffsetOrder order;
     for (int i = 0; i < NSLOTS; ++i) free_q.push(i);
-    size_t num_reads = 0;
-    std::vector<double> dev_busy(ndev, 0.0);
-    std::vector<size_t> dev_batches(ndev, 0);
+    int nfiles_open = 0;
+    for (int i = 0; i < NFILES; ++i) {
+        nfiles_open += out.f[i].is_open() ? 1 : 0;
+        out.f[i].reserved = out.f[i].end;  // (the report's header line is there already)
+    }
+    // the run's regime (the same rule as run_on_device): the value files' text comes from the device, with its size known
+    // before it is copied out -- their places are reserved; or it is formatted on the host and appended in input order.  The
+    // report's lines have a size known from the ids: its places are reserved in every regime.
+    static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
+    const bool no_len_text = o.report_only && !o.ms && o.write_report;
+    const uint32_t run_streams = (no_len_text ? 0u : SPX_TEXT_LENGTHS) | (o.ms ? SPX_TEXT_POINTERS : 0u) | (o.use_doc ? SPX_TEXT_DOCS : 0u);
+    const bool text_run = !host_format && run_streams != 0;
+    auto by_offsets = [&](int f) { return f == F_REPORT || text_run; };
+    std::atomic<size_t> num_reads{0};
+    std::atomic<uint64_t> direct_bytes{0}, staged_bytes{0};
+    // ---- device workers ----
+    std::vector<double> dev_busy(nworkers, 0.0), dev_finish(nworkers, 0.0), dev_wait(nworkers, 0.0);
+    std::vector<size_t> dev_batches(nworkers, 0);
+    std::atomic<uint64_t> next_seq_to_run{0};
     auto device_worker = [&](size_t d) {
         for (;;) {
-            const int i = parsed_q.pop();
+            const uint64_t seq = next_seq_to_run.fetch_add(1);
+            const auto tw = tick();
+            const int i = parsed.look(seq);
+            dev_wait[d] += since(tw);
             if (i < 0) break;
-            const auto t0 = std::chrono::steady_clock::now();
+            parsed.drop(seq);
+            const auto t0 = tick();
             Slot& s = slots[(size_t)i];
-            if (s.sb.nreads() > 0) run_on_device(set.ix[d], o, s.sb, max_value_thr, s.res);
+            // the super-batch's place in the files: reserved once, in input order, as soon as its sizes are known
+            auto place = [&](const uint64_t bytes[3], char* dest[3]) {
+                uint64_t want[NFILES] = {bytes[0], bytes[1], bytes[2], o.write_report ? s.report_bytes : 0};
+                for (int f = 0; f < NFILES; ++f) {
+                    if (!out.f[f].is_open()) want[f] = 0;
+                    s.file_bytes[f] = want[f];
+                }
+                order.reserve(s.seq, out, want, s.file_off);
+                s.placed = true;
+                for (int f = 0; f < 3; ++f)
+                    if (want[f] && out.f[f].pinned && s.file_off[f] + want[f] <= out.f[f].map_size) dest[f] = out.f[f].map + s.file_off[f];
+            };
+            if (s.sb.nreads() > 0) run_on_device(set.ix[d], o, s.sb, max_value_thr, s.res, place);
+            if (!s.placed) {
+                const uint64_t none[3] = {0, 0, 0};
+                char* unused[3] = {nullptr, nullptr, nullptr};
+                s.report_bytes = 0;
+                place(none, unused);
+            }
             if (o.use_promotions || o.use_dna_letters) {
                 // a read that digests to nothing is fatal where the reference meets it (:926-931):
                 // everything before it is still written
@@ -980,90 +1326,147 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded) {
                         s.deferred = 2;
                         s.deferred_msg = std::string(s.sb.ids[q]);
                         s.sb.ids.resize(q);
-                        s.sb.offs.resize(q + 1);
+                        s.sb.offs.n = q + 1;
+                        // (what the super-batch leaves in the files ends before that read)
+                        for (int f = 0; f < 3; ++f)
+                            if (text_run && (run_streams & (1u << f)) && out.f[f].is_open()) s.file_bytes[f] = s.res.line_start[f][q];
+                        uint64_t rb = 0;
+                        for (size_t j = 0; j < q; ++j) rb += report_line_bytes(s.sb.ids[j].size());
+                        if (o.write_report) s.file_bytes[F_REPORT] = rb;
                         break;
                     }
             }
-            dev_busy[d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            dev_busy[d] += since(t0);
+            const auto t1 = tick();
+            finish_batch(pool, o, out, s.sb, s.res, s.chunks, s.file_off, s.pieces);
+            for (int f = 0; f < NFILES; ++f) {
+                uint64_t staged = 0;
+                for (const Piece& pc : s.pieces[f]) staged += pc.n;
+                staged_bytes += staged;
+                if (by_offsets(f)) direct_bytes += s.file_bytes[f] - std::min(staged, s.file_bytes[f]);
+            }
+            dev_finish[d] += since(t1);
             dev_batches[d]++;
+            s.writers_left.store(nfiles_open);
             done.put(s.seq, i);
         }
     };
     std::vector<std::thread> workers;
-    for (size_t d = 0; d < ndev; ++d) workers.emplace_back(device_worker, d);
-    // writer: the streams, in input order; report thread, one super-batch behind: the report lines, the slot's release
-    // and whatever the reference would have stopped at
-    SlotQueue report_q;
-    std::thread writer([&] {
-        std::vector<TextChunk> chunks;  // formatting buffers of the host-formatted path, kept across super-batches
+    for (size_t d = 0; d < nworkers; ++d) workers.emplace_back(device_worker, d);
+    // ---- writers: one per file, in input order.  The last one through with a super-batch makes it final (the files' logical
+    // ends move), raises what the reference would have stopped at -- after every file holds everything before it -- and
+    // gives the slot back.
+    std::vector<double> write_s(NFILES, 0.0);
+    auto file_writer = [&](int f) {
         for (uint64_t seq = 0;; ++seq) {
-            const int i = done.take(seq);
+            const int i = done.look(seq);
             Slot& s = slots[(size_t)i];
-            t_write.start();
-            if (s.sb.nreads() > 0) {
-                if (s.res.device_text) {
-                    if (!s.job) s.job.reset(new TextJob());
-                    write_results_text_begin(out, o, s.sb, s.res, *s.job);
-                } else {
-                    write_results(out, o, s.sb, s.res, chunks);
+            const auto t0 = tick();
+            if (by_offsets(f)) {
+                uint64_t at = s.file_off[f];
+                for (const Piece& pc : s.pieces[f]) {
+                    const uint64_t n = std::min<uint64_t>(pc.n, s.file_off[f] + s.file_bytes[f] - at);  // (a super-batch cut at a fatal read)
+                    out.f[f].write_at(pc.p, n, at);
+                    at += n;
                 }
+            } else {
+                // values formatted on the host: the pieces' sizes were not known when the places were handed out (they were
+                // handed out empty): appended in input order
+                for (const Piece& pc : s.pieces[f]) out.f[f].append(pc.p, pc.n);
             }
-            t_write.stop();
+            write_s[(size_t)f] += since(t0);
             // a super-batch that ends in a deferred fatal (a read empty after digestion is only known once the batch is
-            // back from its device) is the last one written: the report thread, one batch behind, stops the run there,
-            // and nothing of a later super-batch may reach the files before it does (the reference stops AT the read)
+            // back from its device) is the last one written: nothing of a later super-batch may reach the files (the
+            // reference stops AT the read)
             const bool last = s.last || s.deferred != 0;
-            report_q.push(i);
-            if (last) break;
-        }
-    });
-    std::thread reporter([&] {
-        for (;;) {
-            const int i = report_q.pop();
-            Slot& s = slots[(size_t)i];
-            t_report.start();
-            if (s.sb.nreads() > 0 && s.res.device_text && s.job) write_results_text_finish(out, o, *s.job);
-            t_report.stop();
-            num_reads += s.sb.nreads();
-            if (s.deferred == 1) fatal_error("%s", s.deferred_msg.c_str());
-            if (s.deferred == 2) {
-                std::cout << "\n\n";
-                fatal_warning("%s was empty after digestion, commonly due to reads "
-                              "consisting of mostly non-ACGT characters. Please remove "
-                              "read or run SPUMONI without minimizer digestion.", s.deferred_msg.data());
+            if (s.writers_left.fetch_sub(1) == 1) {
+                for (int g = 0; g < NFILES; ++g)
+                    if (out.f[g].is_open() && by_offsets(g)) out.f[g].end = s.file_off[g] + s.file_bytes[g];
+                num_reads += s.sb.nreads();
+                if (s.deferred == 1) fatal_error("%s", s.deferred_msg.c_str());
+                if (s.deferred == 2) {
+                    std::cout << "\n\n";
+                    fatal_warning("%s was empty after digestion, commonly due to reads "
+                                  "consisting of mostly non-ACGT characters. Please remove "
+                                  "read or run SPUMONI without minimizer digestion.", s.deferred_msg.data());
+                }
+                done.drop(seq);
+                if (!last) free_q.push(i);
             }
-            const bool last = s.last;
-            free_q.push(i);
             if (last) break;
         }
-    });
-    bool input_done = false;
-    for (uint64_t seq = 0;; ++seq) {
-        const int i = free_q.pop();
-        t_parse.start();
-        fill_slot(input, o, slots[(size_t)i], input_done);
-        t_parse.stop();
-        slots[(size_t)i].seq = seq;
-        const bool last = slots[(size_t)i].last;
-        parsed_q.push(i);
-        if (last) break;
-    }
-    for (size_t d = 0; d < ndev; ++d) parsed_q.push(-1);
+    };
+    std::vector<std::thread> writers;
+    for (int f = 0; f < NFILES; ++f)
+        if (out.f[f].is_open()) writers.emplace_back(file_writer, f);
+    // ---- feeders ----
+    std::mutex seg_mu;
+    std::atomic<bool> input_done{false};  // (set without the lock by a feeder whose super-batch ends in a fatal read: the other
+                                          // feeder may be waiting for a slot with the lock held)
+    uint64_t next_seq = 0;
+    double seg_s = 0, parse_s[NFEED][2] = {};
+    auto feeder = [&](int fi) {
+        std::vector<ReadFile::Range> ranges;
+        for (;;) {
+            int i;
+            {
+                std::lock_guard<std::mutex> g(seg_mu);
+                if (input_done) return;
+                // (the slot is taken under the lock: super-batch k holds a slot before k + 1 asks for one, so the stages
+                // behind, which want k first, can never be starved of it by later super-batches)
+                i = free_q.pop();
+                const auto t0 = tick();
+                ranges.clear();
+                size_t bytes = 0;
+                while (bytes < o.super_batch_chars) {
+                    ReadFile::Range r;
+                    if (!input.next_range(1000, r)) {  // reader.loadBatch(input_file, 1000)   (:903)
+                        input_done = true;
+                        break;
+                    }
+                    bytes += r.bytes;
+                    ranges.push_back(r);
+                }
+                slots[(size_t)i].seq = next_seq++;
+                slots[(size_t)i].last = input_done;
+                seg_s += since(t0);
+            }
+            Slot& s = slots[(size_t)i];
+            fill_slot(pool, input, ranges, s, parse_s[fi]);
+            if (s.deferred) input_done = true;  // nothing behind a malformed / empty read is part of the run
+            const bool last = s.last;
+            const uint64_t seq = s.seq;
+            parsed.put(seq, i);
+            if (last) {
+                parsed.set_last(seq);
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> feeders;
+    for (int fi = 1; fi < NFEED; ++fi) feeders.emplace_back(feeder, fi);
+    feeder(0);
+    for (auto& t : feeders) t.join();
     for (auto& w : workers) w.join();
-    writer.join();
-    reporter.join();
-    std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte",
-                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count());
-    // per-stage wall times (ours, additive; stages overlap, so they do not add up to the total)
-    for (StageTimer* t : {&t_load, &t_parse, &t_write, &t_report})
-        std::fprintf(stderr, "[timing] %-22s %.3f s\n", t->name, t->total);
-    std::fprintf(stderr, "[timing]   segmentation %.3f  parse %.3f  placement %.3f  copy %.3f s\n", g_parse_s[0], g_parse_s[1],
-                 g_parse_s[2], g_parse_s[3]);
-    std::fprintf(stderr, "[timing] %-22s %.3f s\n", "  of which formatting", g_format_s);
-    for (size_t d = 0; d < ndev; ++d)
-        std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)\n", d,
-                     dev_busy[d], dev_batches[d]);
-    return num_reads;
+    for (auto& w : writers) w.join();
+    settle_outputs(true);  // the files end where their last super-batch does
+    std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
+    // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
+    double p0 = 0, p1 = 0;
+    for (int fi = 0; fi < NFEED; ++fi) p0 += parse_s[fi][0], p1 += parse_s[fi][1];
+    std::fprintf(stderr, "[timing] %-22s %.3f s  (%d feeders on a pool of %zu: segmentation %.3f  scan %.3f  copy %.3f s)\n", "segment+parse",
+                 seg_s + p0 + p1, NFEED, pool.size(), seg_s, p0, p1);
+    static const char* const fname[NFILES] = {"lengths", "pointers", "doc_numbers", "report"};
+    for (int f = 0; f < NFILES; ++f)
+        if (out.f[f].is_open())
+            std::fprintf(stderr, "[timing] writer %-15s %.3f s  (%.1f MB; %s)\n", fname[f], write_s[(size_t)f], (double)out.f[f].end / 1e6,
+                         out.f[f].map_size ? "its tail was prepared as memory" : "plain writes");
+    std::fprintf(stderr, "[timing] output bytes: %.1f MB went straight into the files' pages, %.1f MB through the writer threads (files prepared in %.3f s while the index loaded)\n",
+                 (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s);
+    for (size_t d = 0; d < nworkers; ++d)
+        std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)  + headers / report %.3f s, waiting for input %.3f s\n", d,
+                     dev_busy[d], dev_batches[d], dev_finish[d], dev_wait[d]);
+    return num_reads.load();
 }
 
 size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
@@ -1072,26 +1475,33 @@ size_t classify_general_reads(IndexSet& set, const RunOptions& o) {
     oo.use_doc = false;
     oo.write_report = false;
     Outputs out;
-    out.lengths.open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
-    if (o.ms) out.pointers.open(o.pattern_file + ".pointers");
+    out.f[F_LENGTHS].open(o.pattern_file + (o.ms ? ".lengths" : ".pseudo_lengths"));
+    if (o.ms) out.f[F_POINTERS].open(o.pattern_file + ".pointers");
     std::vector<uint8_t> data;
     if (!read_whole_file(o.pattern_file, data)) fatal_error("The following path is not valid: %s", o.pattern_file.data());
+    Pool pool(std::max<size_t>(1, o.format_threads) - 1);
     SuperBatch sb;
     Results res;
     std::vector<TextChunk> chunks;
+    std::vector<Piece> pieces[NFILES];
     size_t num_reads = 0, start = 0;
     auto flush = [&]() {
         if (sb.nreads() == 0) return;
-        run_on_device(set.ix[0], oo, sb, 0, res);
-        write_results(out, oo, sb, res, chunks);
+        const uint64_t at0[NFILES] = {0, 0, 0, 0};
+        run_on_device(set.ix[0], oo, sb, 0, res, [](const uint64_t*, char**) {});
+        finish_batch(pool, oo, out, sb, res, chunks, at0, pieces);
+        for (int f = 0; f < NFILES; ++f)
+            for (const Piece& pc : pieces[f]) out.f[f].append(pc.p, pc.n);
         sb.clear();
     };
     for (size_t i = 0; i < data.size(); ++i) {
         if (data[i] == 0x01) {
             sb.seqs.append(data.data() + start, i - start);
             sb.offs.push_back(sb.seqs.size());
+            sb.longest = std::max<uint64_t>(sb.longest, i - start);
             sb.own_ids.push_back("read_" + std::to_string(num_reads));
             sb.ids.push_back(sb.own_ids.back());
+            sb.gap.push_back((uint32_t)sb.own_ids.back().size() + 2);
             num_reads++;
             start = i + 1;
             if (sb.seqs.size() >= o.super_batch_chars) flush();

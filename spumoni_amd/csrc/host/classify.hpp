@@ -53,7 +53,14 @@ size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promot
 // returns the number of reads processed.  Output order = input order (the reference's -t 1).
 // preloaded: the reads file, already mapped (while the index was loading); nullptr = map it here.
 class ReadFile;
-size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded = nullptr);
+// The output files, opened under temporary names with their tails prepared as memory -- allocated, mapped, populated and
+// (the value streams) page-locked for the device -- while the index loads: the run then lands its text in the files' pages
+// without a write() (classify.cpp, OutFile).  reads_file_bytes / reads_guess size the estimate; what does not fit is written
+// the ordinary way.  Returns an object without prepared files where that does not apply (general text, SPUMONI_HOST_FORMAT,
+// SPUMONI_MAP_OUTPUT=0, small outputs, a file system that cannot map).
+struct OutputFiles;
+OutputFiles* prepare_outputs(const RunOptions& o, uint64_t reads_file_bytes, uint64_t reads_guess);
+size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded = nullptr, OutputFiles* prepared = nullptr);
 // page-locked buffers for the slots of classify_reads, made ahead of time (a helper thread, while the index loads)
 void prepare_pinned_pool(const RunOptions& o, size_t ndev);
 // general-text driver (:1219-1297): reads separated by \x01, named read_<i>

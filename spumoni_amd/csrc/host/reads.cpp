@@ -38,7 +38,11 @@ void remove_leftovers() {
     g_leftovers.clear();
 }
 
+static void (*g_exit_hook)() = nullptr;
+void set_exit_hook(void (*hook)()) { g_exit_hook = hook; }
+
 [[noreturn]] static void leave(int code) {
+    if (g_exit_hook) g_exit_hook();
     remove_leftovers();
     std::cout.flush();
     std::fflush(nullptr);
@@ -207,62 +211,94 @@ static inline void strip_trailing_space(std::string_view& s) {
 }
 
 // grabNextRead (batch_loader.cpp:78-131) over the lines of one batch
-void ReadFile::parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const {
+void ReadFile::scan_range(const Range& r, std::vector<ReadRec>& out, ParseError& err) const {
     const size_t last = r.last;
     size_t i = r.first;
     auto fail = [&](const std::string& msg) {
         err.fatal = true;
         err.message = msg;
     };
+    const bool fastq = format_ == ReadFormat::Fastq;
     while (i < last) {
-        std::string_view hdr = line(i++);
+        const std::string_view hdr = line(i++);
         if (hdr.empty()) return;  // an empty header line ends the batch (Appendix C15)
-        if (format_ == ReadFormat::Fastq) {
+        if (fastq) {
             if (hdr[0] != '@')
                 return fail(std::string("Incorrect FASTQ entry, it should start with '@' but found ") + hdr[0]);
         } else if (hdr[0] != '>') {
             return fail(std::string("Incorrect FASTA entry, it should start with '>' but found ") + hdr[0]);
         }
         if (hdr.size() <= 2) return fail("header line is missing an id. invalid query cannot be processed.");
-        size_t ws = hdr.find_first_of(" \t\r", 1);
-        if (ws == std::string_view::npos) ws = hdr.size();
-        ParsedRead rd;
-        rd.id = hdr.substr(1, ws);  // count = ws: includes the whitespace character itself
-        if (format_ == ReadFormat::Fastq) {
+        size_t ws = 1;  // first of " \t\r" at or after position 1
+        while (ws < hdr.size() && hdr[ws] != ' ' && hdr[ws] != '\t' && hdr[ws] != '\r') ++ws;
+        ReadRec rd;
+        rd.id = hdr.data() + 1;
+        // header.substr(1, ws): count = ws, i.e. the whitespace character itself is kept (C6), clipped to the line
+        rd.id_len = (uint32_t)std::min(ws, hdr.size() - 1);
+        if (fastq) {
             if (i >= last) return;
-            std::string_view s = line(i++);
+            std::string_view s = line(i);
+            rd.first_line = i++;
             strip_trailing_space(s);
-            rd.one = s;
+            rd.nlines = 1;
+            rd.seq_len = s.size();
             if (i >= last) return;  // '+' line
             i++;
             if (i >= last) return;  // qualities
             i++;
         } else {
-            bool dropped = false;
-            size_t nseq = 0;  // sequence lines of this record
+            rd.first_line = i;
             for (;;) {
                 if (i >= last) {
                     // the reference peeks past the end, getline fails and it returns seq.size():
                     // a record with an empty sequence at the end of a batch is dropped
-                    if (rd.seq().empty()) dropped = true;
+                    if (rd.seq_len == 0) return;
                     break;
                 }
                 std::string_view s = line(i);
                 if (!s.empty() && s[0] == '>') break;
                 i++;
                 strip_trailing_space(s);
-                if (nseq == 0) {
-                    rd.one = s;  // the usual case: one line, no copy
-                } else {
-                    if (!rd.multi) {
-                        rd.multi = true;
-                        rd.joined.assign(rd.one);
-                    }
-                    rd.joined.append(s);
-                }
-                nseq++;
+                rd.seq_len += s.size();
+                rd.nlines++;
             }
-            if (dropped) return;
+        }
+        out.push_back(rd);
+    }
+}
+
+void ReadFile::copy_seq_upper(const ReadRec& rd, uint8_t* dst) const {
+    for (uint32_t l = 0; l < rd.nlines; ++l) {
+        std::string_view s = line(rd.first_line + l);
+        strip_trailing_space(s);
+        const unsigned char* src = (const unsigned char*)s.data();
+        const size_t len = s.size();
+        for (size_t i = 0; i < len; ++i) {
+            const unsigned char ch = src[i];
+            dst[i] = (uint8_t)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
+        }
+        dst += len;
+    }
+}
+
+// the same with the reads as objects (dump-reads, next_batch): views for single-line records, a joined copy otherwise
+void ReadFile::parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const {
+    std::vector<ReadRec> recs;
+    scan_range(r, recs, err);
+    for (const ReadRec& rc : recs) {
+        ParsedRead rd;
+        rd.id = std::string_view(rc.id, rc.id_len);
+        if (rc.nlines <= 1) {
+            std::string_view s = rc.nlines ? line(rc.first_line) : std::string_view();
+            strip_trailing_space(s);
+            rd.one = s;
+        } else {
+            rd.multi = true;
+            for (uint32_t l = 0; l < rc.nlines; ++l) {
+                std::string_view s = line(rc.first_line + l);
+                strip_trailing_space(s);
+                rd.joined.append(s);
+            }
         }
         out.push_back(std::move(rd));
     }

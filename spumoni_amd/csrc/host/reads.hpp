@@ -28,6 +28,16 @@ struct ParsedRead {
     std::string_view seq() const { return multi ? std::string_view(joined) : one; }
 };
 
+// The same read as positions in the mapped file and nothing else (32 bytes, no constructor): what the harness parses
+// super-batches into -- 10^7 reads a second have to come out of the parser, and a ParsedRead carries a std::string.
+struct ReadRec {
+    const char* id = nullptr;  // as ParsedRead::id
+    uint32_t id_len = 0;
+    uint32_t nlines = 0;       // sequence lines (FASTQ: 1; FASTA: as many as the record has)
+    uint64_t seq_len = 0;      // characters of the sequence, trailing whitespace of every line stripped
+    size_t first_line = 0;     // index of the first sequence line
+};
+
 class ReadFile {
 public:
     // Maps the file and finds its lines (several threads); throws std::runtime_error if it cannot be read.
@@ -59,8 +69,17 @@ public:
     // done on the thread that maps the file while the index loads; next_range(num_bases) then hands the ranges out.
     void precompute_ranges(size_t num_bases);
     void parse_range(const Range& r, std::vector<ParsedRead>& out, ParseError& err) const;
+    // grabNextRead over the lines of one batch, reads appended to `out` as positions (parse_range is this plus copies)
+    void scan_range(const Range& r, std::vector<ReadRec>& out, ParseError& err) const;
+    // the read's sequence, upper-cased (::toupper in the "C" locale, compute_ms_pml.cpp:916-917), to dst[0 .. seq_len)
+    void copy_seq_upper(const ReadRec& rd, uint8_t* dst) const;
+    // every range of the file at once (precompute_ranges must have run): the feeders cut super-batches out of it
+    bool ranges_ready(size_t num_bases) const { return ranges_ready_ && num_bases == ranges_bases_; }
 
     ReadFormat format() const { return format_; }
+    size_t file_bytes() const { return size_; }
+    char first_char() const { return size_ ? data_[0] : '\0'; }  // ('@': FASTQ, batch_loader.cpp:30-38)
+    size_t lines() const { return line_start_.size() - 1; }
 
 private:
     const char* data_ = nullptr;  // the mapped file
@@ -84,6 +103,7 @@ private:
 // error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)
 void register_leftover(const std::string& path);  // a file to be gone when the process ends, however it ends
 void remove_leftovers();
+void set_exit_hook(void (*hook)());               // called once on every way out through fatal_error / fatal_warning
 [[noreturn]] void fatal_error(const char* fmt, ...);
 [[noreturn]] void fatal_warning(const char* fmt, ...);
 

@@ -13,6 +13,7 @@
 #include <getopt.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -188,13 +189,22 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     auto start_time = std::chrono::system_clock::now();
     // the reads file is mapped and its lines are indexed on another thread while the index loads
     std::unique_ptr<ReadFile> reads;
+    OutputFiles* outputs = nullptr;
     std::string reads_err;
     std::thread reads_loader;
     if (!o.is_general_text)
         reads_loader = std::thread([&] {
             try {
                 reads.reset(new ReadFile(o.pattern_file, (unsigned)o.format_threads));
+                // the output files' tails as memory, sized from the reads file (classify.cpp: prepare_outputs), beside the
+                // segmentation below and the index load on the main thread
+                std::thread prep([&] {
+                    const uint64_t nlines = reads->lines();
+                    const bool fastq = reads->first_char() == '@';
+                    outputs = prepare_outputs(o, reads->file_bytes(), fastq ? nlines / 4 : nlines / 2);
+                });
                 reads->precompute_ranges(1000);  // reader.loadBatch(input_file, 1000)   (compute_ms_pml.cpp:903)
+                prep.join();
             } catch (const std::exception& e) {
                 reads_err = e.what();
             }
@@ -238,7 +248,7 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     }
     start_time = std::chrono::system_clock::now();
     STATUS_LOG(tag, o.ms ? "processing the reads" : "processing the patterns");
-    size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o, reads.get());
+    size_t num_reads = o.is_general_text ? classify_general_reads(set, o) : classify_reads(set, o, reads.get(), outputs);
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     FORCE_LOG(tag, "finished processing %d reads. results are saved in *.%s file.", (int)num_reads,
               o.ms ? "lengths" : "pseudo_lengths");
@@ -255,12 +265,24 @@ static int run_main(int argc, char** argv) {
     validate(o);
     o.ref_file += o.use_promotions ? ".bin" : ".fa";  // spumoni.cpp:744-747
     o.ms = (o.result_type == 0);
+    // SPUMONI_GPUS: the device of every WORKER (a host thread that feeds a device from the one queue of parsed
+    // super-batches).  Two entries that name the same device are two query contexts over one copy of the index: one's
+    // copies over PCIe run under the other's kernels.  Default: "0,0"; "all": every visible device, twice.
+    o.devices = {0, 0};
     if (const char* g = std::getenv("SPUMONI_GPUS")) {
         o.devices.clear();
-        std::stringstream ss(g);
-        std::string tok;
-        while (std::getline(ss, tok, ','))
-            if (!tok.empty()) o.devices.push_back(std::atoi(tok.c_str()));
+        if (std::strcmp(g, "all") == 0) {
+            const int nd = std::max(1, spx_device_count());
+            for (int d = 0; d < nd; ++d) {
+                o.devices.push_back(d);
+                o.devices.push_back(d);
+            }
+        } else {
+            std::stringstream ss(g);
+            std::string tok;
+            while (std::getline(ss, tok, ','))
+                if (!tok.empty()) o.devices.push_back(std::atoi(tok.c_str()));
+        }
         if (o.devices.empty()) o.devices.push_back(0);
     }
     if (const char* t = std::getenv("SPUMONI_TEXT")) o.text_file = t;
@@ -272,7 +294,15 @@ static int run_main(int argc, char** argv) {
     if (const char* t = std::getenv("SPUMONI_SUPER_BATCH")) o.super_batch_chars = std::max<size_t>(1000, std::strtoull(t, nullptr, 10));
     // -t: the reference's helper threads walk the index; here the GPU does, and the threads
     // format the output text instead (default: up to 16 of the available cores)
-    o.format_threads = o.threads > 1 ? o.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    // (sixteen per distinct device: the feeders' parsing, the headers and the report are what the host does per read, and
+    // every device wants its share of cores for them -- SURVEY 8(e): one feeder thread group per GPU)
+    {
+        std::vector<int> distinct = o.devices;
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        const unsigned want = 16u * (unsigned)std::max<size_t>(1, distinct.size());
+        o.format_threads = o.threads > 1 ? o.threads : std::max(1u, std::min(want, std::thread::hardware_concurrency()));
+    }
     return run_spumoni(o);
 }
 

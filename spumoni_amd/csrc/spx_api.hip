@@ -111,11 +111,20 @@ int spx_device_count(void) { return usable_devices(); }
 void spx_index_free(spx_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    void** arr[spx_index::NARR];
-    index_arrays(ix, arr);
-    for (void** a : arr)
-        if (*a) (void)hipFree(*a);
+    if (ix->owner) {
+        ix->owner.reset();  // shared with same-device clones: the last handle frees the arrays
+    } else {
+        void** arr[spx_index::NARR];
+        index_arrays(ix, arr);
+        for (void** a : arr)
+            if (*a) (void)hipFree(*a);
+    }
     if (ix->counters) (void)hipFree(ix->counters);
+    if (ix->ctx_stream) (void)hipStreamDestroy(ix->ctx_stream);
+    if (ix->pool) {
+        (void)hipDeviceSynchronize();  // (stream-ordered frees into the pool are behind us)
+        (void)hipMemPoolDestroy(ix->pool);
+    }
     for (auto& st : ix->pipe_s)
         if (st) (void)hipStreamDestroy(st);
     for (int c = 0; c < spx_index::PIPE_CHUNKS; ++c) {
@@ -144,6 +153,25 @@ static void default_charhash(uint8_t out[4]) {
     out[3] = table['T'];
 }
 
+// the stream of the handle's host-buffer queries (created on first use; callers hold host_mu)
+static int ctx_stream_of(spx_index* ix, hipStream_t* out) {
+    if (!ix->ctx_stream) SPX_HIP(hipStreamCreateWithFlags(&ix->ctx_stream, hipStreamNonBlocking));
+    *out = ix->ctx_stream;
+    return SPX_OK;
+}
+
+// The text is one of the shared arrays: it can only be replaced while no same-device clone reads it (callers hold mu).
+static int own_arrays_alone(spx_index* ix) {
+    if (!ix->owner) return SPX_OK;
+    if (ix->owner.use_count() > 1) {
+        set_error("the index shares its arrays with a clone on the same device: set or rebuild the text before cloning");
+        return SPX_E_ARG;
+    }
+    for (void*& a : ix->owner->p) a = nullptr;  // back to plain ownership by this handle
+    ix->owner.reset();
+    return SPX_OK;
+}
+
 // counters, events and knobs every index carries, however its arrays came to be
 static int init_runtime(spx_index* ix) {
     default_charhash(ix->charhash);
@@ -154,14 +182,22 @@ static int init_runtime(spx_index* ix) {
     SPX_HIP(hipEventCreate(&ix->ev1));
     SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
     {
-        // The stream-ordered scratch of the digestion (hipMallocAsync: the parked bytes, the scans' workspace) comes from the
-        // device's default pool, which by default hands freed memory back to the system at the next synchronisation -- and
-        // maps it again at the next call: tens of milliseconds for a 2 GB block, on and off (a 2 ms digestion was seen to take
-        // 37-71 ms in whole runs of tools/digest_bench.py).  The pool keeps up to 4 GB of what it has been given.
-        hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, ix->device) == hipSuccess && pool) {
+        // The stream-ordered scratch of the digestion (the parked bytes, the scans' workspace) comes from a pool of the
+        // handle's own.  A pool by default hands freed memory back to the system at the next synchronisation -- and maps it
+        // again at the next call: tens of milliseconds for a 2 GB block, on and off (a 2 ms digestion was seen to take
+        // 37-71 ms in whole runs of tools/digest_bench.py) -- so this one keeps up to 4 GB of what it has been given; it goes
+        // with the handle (round 4 set the threshold on the device's default pool, for the whole process and for good).
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = ix->device;
+        if (hipMemPoolCreate(&ix->pool, &props) == hipSuccess && ix->pool) {
             uint64_t keep = 4ull << 30;  // (up to 4 GB: a batch's scratch, not what a one-off giant call asked for)
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            (void)hipMemPoolSetAttribute(ix->pool, hipMemPoolAttrReleaseThreshold, &keep);
+        } else {
+            ix->pool = nullptr;  // (the default pool then, with its default threshold: correct, slower)
         }
         (void)hipGetLastError();
     }
@@ -301,6 +337,10 @@ int spx_index_set_text(spx_index* ix, const uint8_t* text, uint64_t n_text, int 
     }
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
+    {
+        const int rc_own = own_arrays_alone(ix);
+        if (rc_own != SPX_OK) return rc_own;
+    }
     if (ix->text) (void)hipFree(ix->text);
     ix->text = nullptr;
     ix->n_text = 0;
@@ -376,6 +416,10 @@ int spx_index_rebuild_text(spx_index* ix) {
     std::lock_guard<std::mutex> g(ix->mu);
     SPX_HIP(hipSetDevice(ix->device));
     const uint64_t n_text = ix->n - 1;
+    {
+        const int rc_own = own_arrays_alone(ix);
+        if (rc_own != SPX_OK) return rc_own;
+    }
     if (ix->text) (void)hipFree(ix->text);
     ix->text = nullptr;
     ix->n_text = 0;
@@ -449,6 +493,33 @@ void* spx_host_alloc(size_t bytes) {
 
 void spx_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+int spx_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) {
+        set_error("null argument");
+        return SPX_E_ARG;
+    }
+    if (usable_devices() <= 0) {
+        set_error("no HIP device visible: libspumoni_gpu has no CPU fallback");
+        return SPX_E_NODEVICE;
+    }
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return hip_fail(e, "hipHostRegister", __FILE__, __LINE__);
+    }
+    return SPX_OK;
+}
+
+int spx_host_unregister(void* p) {
+    if (!p) return SPX_OK;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return hip_fail(e, "hipHostUnregister", __FILE__, __LINE__);
+    }
+    return SPX_OK;
 }
 
 int spx_set_option(spx_index* ix, const char* key, int64_t value) {
@@ -596,20 +667,25 @@ int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 0, cap, &dout)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    hipStream_t st = nullptr;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpyAsync(dseq, seqs, total, hipMemcpyHostToDevice, st));
+    SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     rc = spx_digest_batch_device(ix, kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total,
-                                 (uint8_t*)dout, cap, (uint64_t*)dooff, nullptr);
+                                 (uint8_t*)dout, cap, (uint64_t*)dooff, st);
     if (rc != SPX_OK) return rc;
-    SPX_HIP(hipDeviceSynchronize());
-    SPX_HIP(hipMemcpy(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpyAsync(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
     const uint64_t dtotal = out_offsets[nreads];
     if (dtotal > out_capacity || (dtotal && !out_seqs)) {
         set_error("out_seqs holds %llu bytes, the digested reads need %llu", (unsigned long long)out_capacity,
                   (unsigned long long)dtotal);
         return SPX_E_ARG;
     }
-    if (dtotal) SPX_HIP(hipMemcpy(out_seqs, dout, dtotal, hipMemcpyDeviceToHost));
+    if (dtotal) {
+        SPX_HIP(hipMemcpyAsync(out_seqs, dout, dtotal, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
+    }
     return SPX_OK;
 }
 
@@ -666,7 +742,7 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
                              uint64_t nreads, uint64_t total_chars, uint32_t* d_out_lengths,
                              uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class,
                              uint64_t bin_width, uint64_t max_value_thr, void* stream, bool narrow,
-                             const uint64_t* d_in_starts = nullptr) {
+                             const uint64_t* d_in_starts = nullptr, uint64_t geom_chars = 0) {
     int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs,
                          d_out_class, bin_width);
     if (rc != SPX_OK) return rc;
@@ -704,7 +780,9 @@ static int query_device_impl(spx_index* ix, int mode, const uint8_t* d_seqs, con
     SPX_HIP(hipEventRecord(ix->ev0, st));
     bool chunked = false, wrote = false;
     if (nreads > 0) {
-        if (!d_in_starts && (rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked)) != SPX_OK) return rc;
+        // (geom_chars: what the batch is expected to hold when total_chars is only an upper bound -- reads digested on the
+        // device a moment ago; it shapes the chunks, total_chars sizes the scratch)
+        if (!d_in_starts && (rc = launch_walk_chunked(ix, mode, a, total_chars, st, &chunked, geom_chars)) != SPX_OK) return rc;
         if (!chunked && (rc = launch_walk(ix, mode, a, total_chars, st, &wrote)) != SPX_OK) return rc;
     }
     SPX_HIP(hipEventRecord(ix->ev1, st));
@@ -751,16 +829,18 @@ static int run_and_fetch(spx_index* ix, int mode, const uint8_t* d_seq, const ui
     if (out_pointers && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &dptr)) != SPX_OK) return rc;
     if (out_docs && (rc = ensure_scratch(ix, 4, (total + 1) * 4, &ddoc)) != SPX_OK) return rc;
     if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
+    hipStream_t st = nullptr;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
     rc = query_device_impl(ix, mode, d_seq, d_off, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr,
-                           (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, nullptr, width == 2, d_in_starts);
+                           (uint32_t*)ddoc, (spx_class*)dcls, bin_width, max_value_thr, st, width == 2, d_in_starts);
     if (rc != SPX_OK) return rc;
-    SPX_HIP(hipDeviceSynchronize());
-    if (out_lengths) SPX_HIP(hipMemcpy(out_lengths, dlen, total * width, hipMemcpyDeviceToHost));
-    if (out_pointers) SPX_HIP(hipMemcpy(out_pointers, dptr, total * 8, hipMemcpyDeviceToHost));
-    if (out_docs) SPX_HIP(hipMemcpy(out_docs, ddoc, total * width, hipMemcpyDeviceToHost));
-    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
+    if (out_lengths) SPX_HIP(hipMemcpyAsync(out_lengths, dlen, total * width, hipMemcpyDeviceToHost, st));
+    if (out_pointers) SPX_HIP(hipMemcpyAsync(out_pointers, dptr, total * 8, hipMemcpyDeviceToHost, st));
+    if (out_docs) SPX_HIP(hipMemcpyAsync(out_docs, ddoc, total * width, hipMemcpyDeviceToHost, st));
+    if (out_class) SPX_HIP(hipMemcpyAsync(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost, st));
     WalkCounters wc;
-    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
+    SPX_HIP(hipMemcpyAsync(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
     if (wc.error) {
         set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
                   "thresholds are inconsistent with the BWT%s)", wc.error,
@@ -969,9 +1049,11 @@ static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const u
     if (pipelined)
         return run_pipelined(ix, mode, seqs, offsets, nreads, (uint8_t*)dseq, (uint64_t*)doff, padded, out_lengths,
                              out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
-    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemset((char*)dseq + total, 0, padded - total));
-    SPX_HIP(hipMemcpy(dseq, seqs, total, hipMemcpyHostToDevice));
+    hipStream_t st = nullptr;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
+    SPX_HIP(hipMemsetAsync((char*)dseq + total, 0, padded - total, st));
+    SPX_HIP(hipMemcpyAsync(dseq, seqs, total, hipMemcpyHostToDevice, st));
     return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
                          out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
 }
@@ -1011,13 +1093,16 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 0, cap, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(draw, seqs, total, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
+    hipStream_t st = nullptr;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    SPX_HIP(hipMemcpyAsync(draw, seqs, total, hipMemcpyHostToDevice, st));
+    SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     const uint64_t* in_starts = nullptr;
     rc = digest_for_walk(ix, mode, out_lengths != nullptr, kind, k, w, (const uint8_t*)draw, (const uint64_t*)doff, nreads, total,
-                         (uint8_t*)dseq, cap, (uint64_t*)dooff, nullptr, &in_starts);
+                         (uint8_t*)dseq, cap, (uint64_t*)dooff, st, &in_starts);
     if (rc != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost));  // synchronises
+    SPX_HIP(hipMemcpyAsync(out_offsets, dooff, (nreads + 1) * 8, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
     const uint64_t dtotal = out_offsets[nreads];
     if (dtotal > out_capacity) {
         set_error("output buffers hold %llu entries, the digested reads have %llu characters",
@@ -1038,12 +1123,24 @@ static int digest_query_device_impl(spx_index* ix, int mode, int kind, uint32_t 
                                     uint64_t* d_out_pointers, uint32_t* d_out_docs, spx_class* d_out_class, uint64_t bin_width,
                                     uint64_t max_value_thr, void* stream, bool narrow) {
     const uint64_t* in_starts = nullptr;
-    int rc = digest_for_walk(ix, mode, d_out_lengths != nullptr, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_digested,
-                             digested_capacity, d_out_offsets, stream, &in_starts);
+    // everything the walk would refuse is refused BEFORE the digestion is enqueued (a misaligned d_digested
+    // used to take the digestion's dword stores first and the error afterwards)
+    int rc = check_query(ix, mode, d_seqs, d_offsets, d_out_lengths, d_out_pointers, d_out_docs, d_out_class, bin_width);
     if (rc != SPX_OK) return rc;
-    // (total_chars bounds the digested characters: it only sizes the walk's scratch)
+    if ((((uintptr_t)d_digested | (uintptr_t)d_out_lengths | (uintptr_t)d_out_pointers | (uintptr_t)d_out_docs) & 15) != 0) {
+        set_error("d_digested and the output buffers must be 16-byte aligned");
+        return SPX_E_ARG;
+    }
+    rc = digest_for_walk(ix, mode, d_out_lengths != nullptr, kind, k, w, d_seqs, d_offsets, nreads, total_chars, d_digested,
+                         digested_capacity, d_out_offsets, stream, &in_starts);
+    if (rc != SPX_OK) return rc;
+    // total_chars bounds the digested characters and sizes the walk's scratch; the chunked walk's geometry (is the batch
+    // long reads at all, how long is a chunk) goes by what a digestion leaves: about two minimizers per window of
+    // w - k + 1 k-mers, k letters each with -a
+    const uint64_t per = (kind == SPX_DIGEST_DNA ? (uint64_t)k : 1ull) * 2;
+    const uint64_t est = std::min<uint64_t>(total_chars, total_chars * per / (uint64_t)(w - k + 2) + nreads);
     return query_device_impl(ix, mode, d_digested, d_out_offsets, nreads, total_chars, d_out_lengths, d_out_pointers, d_out_docs,
-                             d_out_class, bin_width, max_value_thr, stream, narrow, in_starts);
+                             d_out_class, bin_width, max_value_thr, stream, narrow, in_starts, est);
 }
 
 int spx_digest_query_batch_device(spx_index* ix, int mode, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs,
@@ -1093,9 +1190,11 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     static const bool timing = getenv("SPX_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now();
+    hipStream_t st = nullptr;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
     auto lap = [&](const char* what) {
         if (!timing) return;
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(st);
         const double t = now();
         fprintf(stderr, "[spx] text_begin: %-28s %.2f ms\n", what, (t - t_mark) * 1e3);
         t_mark = t;
@@ -1106,10 +1205,10 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     if ((rc = ensure_scratch(ix, digest_kind ? 6 : 0, padded, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 8, (nreads + 1) * 4, &dgap)) != SPX_OK) return rc;
-    SPX_HIP(hipMemcpy(dseq, seqs, total_in, hipMemcpyHostToDevice));
-    SPX_HIP(hipMemset((char*)dseq + total_in, 0, padded - total_in));
-    SPX_HIP(hipMemcpy(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice));
-    if (gap) SPX_HIP(hipMemcpy(dgap, gap, nreads * 4, hipMemcpyHostToDevice));
+    SPX_HIP(hipMemcpyAsync(dseq, seqs, total_in, hipMemcpyHostToDevice, st));
+    SPX_HIP(hipMemsetAsync((char*)dseq + total_in, 0, padded - total_in, st));
+    SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
+    if (gap) SPX_HIP(hipMemcpyAsync(dgap, gap, nreads * 4, hipMemcpyHostToDevice, st));
     lap("copy in");
     const uint8_t* wseq = (const uint8_t*)dseq;
     const uint64_t* woff = (const uint64_t*)doff;
@@ -1125,9 +1224,10 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         if ((rc = ensure_scratch(ix, 0, cap, &dd)) != SPX_OK) return rc;
         if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &ddo)) != SPX_OK) return rc;
         rc = digest_for_walk(ix, mode, want_len || out_class != nullptr, digest_kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff,
-                             nreads, total_in, (uint8_t*)dd, cap, (uint64_t*)ddo, nullptr, &in_starts);
+                             nreads, total_in, (uint8_t*)dd, cap, (uint64_t*)ddo, st, &in_starts);
         if (rc != SPX_OK) return rc;
-        SPX_HIP(hipMemcpy(&total, (uint64_t*)ddo + nreads, 8, hipMemcpyDeviceToHost));  // synchronises
+        SPX_HIP(hipMemcpyAsync(&total, (uint64_t*)ddo + nreads, 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipStreamSynchronize(st));
         wseq = (const uint8_t*)dd;
         woff = (const uint64_t*)ddo;
     }
@@ -1138,7 +1238,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     if (want_doc && (rc = ensure_scratch(ix, 4, (total + 8) * 4, &ddoc)) != SPX_OK) return rc;
     if (out_class && (rc = ensure_scratch(ix, 5, (nreads + 1) * sizeof(spx_class), &dcls)) != SPX_OK) return rc;
     rc = query_device_impl(ix, mode, wseq, woff, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr, (uint32_t*)ddoc,
-                           (spx_class*)dcls, bin_width, max_value_thr, nullptr, narrow, in_starts);
+                           (spx_class*)dcls, bin_width, max_value_thr, st, narrow, in_starts);
     if (rc != SPX_OK) return rc;
     lap("[digest +] walk");
     // count + scan per stream, then ONE read-back of the three sizes
@@ -1155,26 +1255,28 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         if ((rc = ensure_scratch(ix, 10 + i, (nreads + 2) * 8, &lb[i])) != SPX_OK) return rc;
         if ((rc = ensure_scratch(ix, 13 + i, (nreads + 2) * 8, &ls[i])) != SPX_OK) return rc;
         if ((rc = launch_text_count(vals[i], vbytes[i], woff, gap ? (const uint32_t*)dgap : nullptr, nreads, (uint64_t*)lb[i],
-                                    (uint64_t*)ls[i], dcub, cub, nullptr)) != SPX_OK)
+                                    (uint64_t*)ls[i], dcub, cub, st)) != SPX_OK)
             return rc;
     }
     for (int i = 0; i < 3; ++i)
-        if (vals[i]) SPX_HIP(hipMemcpy(&out_bytes[i], (uint64_t*)ls[i] + nreads, 8, hipMemcpyDeviceToHost));
+        if (vals[i]) SPX_HIP(hipMemcpyAsync(&out_bytes[i], (uint64_t*)ls[i] + nreads, 8, hipMemcpyDeviceToHost, st));
+    // the class records and the counters are ready since the walk: they travel under the digits' kernels
+    WalkCounters wc;
+    if (out_class) SPX_HIP(hipMemcpyAsync(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipMemcpyAsync(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost, st));
+    SPX_HIP(hipStreamSynchronize(st));
     lap("count + scan");
     for (int i = 0; i < 3; ++i) {
         if (!vals[i]) continue;
         void* dtext = nullptr;
         if ((rc = ensure_scratch(ix, 16 + i, out_bytes[i] + 64, &dtext)) != SPX_OK) return rc;
         if ((rc = launch_text_write(vals[i], vbytes[i], woff, gap ? (const uint32_t*)dgap : nullptr, nreads,
-                                    (const uint64_t*)ls[i], (char*)dtext, nullptr)) != SPX_OK)
+                                    (const uint64_t*)ls[i], (char*)dtext, st)) != SPX_OK)
             return rc;
         ix->text_bytes[i] = out_bytes[i];
     }
-    SPX_HIP(hipDeviceSynchronize());
+    // (not waited for: spx_query_text_fetch copies on the same stream, behind the digits)
     lap("digits");
-    if (out_class) SPX_HIP(hipMemcpy(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost));
-    WalkCounters wc;
-    SPX_HIP(hipMemcpy(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost));
     if (wc.error) {
         set_error("the walk hit %llu undefined steps (predecessor jump without a predecessor run: "
                   "thresholds are inconsistent with the BWT)", wc.error);
@@ -1196,14 +1298,20 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
         return SPX_E_ARG;
     }
     SPX_HIP(hipSetDevice(ix->device));
+    hipStream_t st = nullptr;
+    {
+        const int rc = ctx_stream_of(ix, &st);
+        if (rc != SPX_OK) return rc;
+    }
     static const bool timing = getenv("SPX_TIMING") != nullptr;
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     for (int i = 0; i < 3; ++i) {
         if (ix->text_bytes[i] == 0) continue;
-        if (text[i]) SPX_HIP(hipMemcpy(text[i], ix->scratch[16 + i].p, ix->text_bytes[i], hipMemcpyDeviceToHost));
+        if (text[i]) SPX_HIP(hipMemcpyAsync(text[i], ix->scratch[16 + i].p, ix->text_bytes[i], hipMemcpyDeviceToHost, st));
         if (line_start && line_start[i])
-            SPX_HIP(hipMemcpy(line_start[i], ix->scratch[13 + i].p, (ix->text_nreads + 1) * 8, hipMemcpyDeviceToHost));
+            SPX_HIP(hipMemcpyAsync(line_start[i], ix->scratch[13 + i].p, (ix->text_nreads + 1) * 8, hipMemcpyDeviceToHost, st));
     }
+    SPX_HIP(hipStreamSynchronize(st));
     ix->text_ready = false;
     if (timing)
         fprintf(stderr, "[spx] text_fetch: %.2f ms for %.1f MB\n",
@@ -1569,13 +1677,29 @@ spx_index* spx_index_clone(spx_index* src, int device) {
         void** to[spx_index::NARR];
         index_arrays(src, from);
         index_arrays(ix, to);
-        for (int i = 0; i < spx_index::NARR; ++i) {
-            ix->arr_bytes[i] = src->arr_bytes[i];
-            if (src->arr_bytes[i] == 0) continue;
-            SPX_HIP(hipMalloc(to[i], src->arr_bytes[i]));
-            SPX_HIP(hipMemcpyPeerAsync(*to[i], device, *from[i], src->device, src->arr_bytes[i], nullptr));
+        if (device == src->device) {
+            // the same device: a second query context over the same arrays (nothing is copied; the arrays are read-only
+            // once built and go when the last handle is freed) -- what lets two host threads keep one device's copy engines
+            // and compute units busy at the same time without a second 200 GB replica
+            if (!src->owner) {
+                src->owner = std::make_shared<ArrayOwner>();
+                src->owner->device = src->device;
+                for (int i = 0; i < spx_index::NARR; ++i) src->owner->p[i] = *from[i];
+            }
+            ix->owner = src->owner;
+            for (int i = 0; i < spx_index::NARR; ++i) {
+                ix->arr_bytes[i] = src->arr_bytes[i];
+                *to[i] = *from[i];
+            }
+        } else {
+            for (int i = 0; i < spx_index::NARR; ++i) {
+                ix->arr_bytes[i] = src->arr_bytes[i];
+                if (src->arr_bytes[i] == 0) continue;
+                SPX_HIP(hipMalloc(to[i], src->arr_bytes[i]));
+                SPX_HIP(hipMemcpyPeerAsync(*to[i], device, *from[i], src->device, src->arr_bytes[i], nullptr));
+            }
+            SPX_HIP(hipDeviceSynchronize());
         }
-        SPX_HIP(hipDeviceSynchronize());
         bind_view(ix);
         const int rc = init_runtime(ix);
         memcpy(ix->charhash, src->charhash, sizeof ix->charhash);

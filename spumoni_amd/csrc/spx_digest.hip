@@ -738,6 +738,37 @@ __global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* 
 
 }  // namespace
 
+// Stream-ordered scratch that is given back on every way out of launch_digest (an error between the
+// allocations and the frees used to leak up to seven blocks per call).
+namespace {
+struct AsyncScratch {
+    hipStream_t st;
+    hipMemPool_t pool;
+    void* p[12] = {};
+    int n = 0;
+    AsyncScratch(hipStream_t s, hipMemPool_t pl) : st(s), pool(pl) {}
+    AsyncScratch(const AsyncScratch&) = delete;
+    AsyncScratch& operator=(const AsyncScratch&) = delete;
+    hipError_t get(void** out, size_t bytes) {
+        if (n >= 12) return hipErrorOutOfMemory;
+        const hipError_t e = pool ? hipMallocFromPoolAsync(out, bytes ? bytes : 16, pool, st) : hipMallocAsync(out, bytes ? bytes : 16, st);
+        if (e == hipSuccess) p[n++] = *out;
+        return e;
+    }
+    void release_now(void* q) {  // freed in stream order right away (and not again by the destructor)
+        for (int i = 0; i < n; ++i)
+            if (p[i] == q) {
+                (void)hipFreeAsync(q, st);
+                p[i] = nullptr;
+            }
+    }
+    ~AsyncScratch() {
+        for (int i = 0; i < n; ++i)
+            if (p[i]) (void)hipFreeAsync(p[i], st);
+    }
+};
+}  // namespace
+
 int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* d_seqs, const uint64_t* d_offs,
                   uint64_t nreads, uint64_t total_chars, uint8_t* d_out, uint64_t* d_out_offs, hipStream_t st, bool* parked) {
     // *parked (in): the caller is the walk itself and can take the digested reads where the digestion parks them -- read
@@ -791,6 +822,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     a.counts = d_out_offs;
     a.out_offs = d_out_offs;
     a.out = d_out;
+    AsyncScratch scr(st, ix->pool);
     SPX_HIP(hipMemsetAsync(d_out_offs, 0, 8, st));
     if (nreads == 0) {
         k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, 0, d_out);
@@ -807,9 +839,9 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         size_t tmp_bytes = 0;
         SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
         void* tmp = nullptr;
-        SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+        SPX_HIP(scr.get(&tmp, tmp_bytes));
         SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
-        SPX_HIP(hipFreeAsync(tmp, st));
+        scr.release_now(tmp);
         return SPX_OK;
     };
     // long reads of the default shape: a lane per chunk of 240 characters (k_digest_chunks)
@@ -823,13 +855,13 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         uint64_t *first_chunk = nullptr, *c_start = nullptr, *c_count = nullptr, *rcount = nullptr;
         uint32_t *c_rd = nullptr, *bad = nullptr;
         uint8_t* stash = nullptr;
-        SPX_HIP(hipMallocAsync((void**)&first_chunk, (nreads + 2) * 8, st));
-        SPX_HIP(hipMallocAsync((void**)&rcount, (nreads + 2) * 8, st));
-        SPX_HIP(hipMallocAsync((void**)&bad, (nreads + 1) * 4, st));
-        SPX_HIP(hipMallocAsync((void**)&c_start, (bound + 2) * 8, st));
-        SPX_HIP(hipMallocAsync((void**)&c_count, (bound + 2) * 8, st));
-        SPX_HIP(hipMallocAsync((void**)&c_rd, (bound + 2) * 4, st));
-        SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
+        SPX_HIP(scr.get((void**)&first_chunk, (nreads + 2) * 8));
+        SPX_HIP(scr.get((void**)&rcount, (nreads + 2) * 8));
+        SPX_HIP(scr.get((void**)&bad, (nreads + 1) * 4));
+        SPX_HIP(scr.get((void**)&c_start, (bound + 2) * 8));
+        SPX_HIP(scr.get((void**)&c_count, (bound + 2) * 8));
+        SPX_HIP(scr.get((void**)&c_rd, (bound + 2) * 4));
+        SPX_HIP(scr.get((void**)&stash, total_chars + 64));
         auto scan = [&](uint64_t* v, uint64_t count, bool inclusive) -> int {
             size_t tmp_bytes = 0;
             void* tmp = nullptr;
@@ -837,12 +869,12 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
                 SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, v, v, count, st));
             else
                 SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, v, v, count, st));
-            SPX_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+            SPX_HIP(scr.get(&tmp, tmp_bytes));
             if (inclusive)
                 SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, v, v, count, st));
             else
                 SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, v, v, count, st));
-            SPX_HIP(hipFreeAsync(tmp, st));
+            scr.release_now(tmp);
             return SPX_OK;
         };
         const unsigned gq = (unsigned)((nreads + 1 + 255) / 256), gc = (unsigned)((bound + 255) / 256);
@@ -884,8 +916,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         aw.out = d_out;
         k_digest_wave<1><<<gridw, 64, lds, st>>>(aw);
         SPX_HIP(hipGetLastError());
-        for (void* p : {(void*)first_chunk, (void*)rcount, (void*)bad, (void*)c_start, (void*)c_count, (void*)c_rd, (void*)stash})
-            SPX_HIP(hipFreeAsync(p, st));
+        // (the scratch goes back when `scr` does: in stream order, behind the kernels above)
         k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
         SPX_HIP(hipGetLastError());
         return SPX_OK;
@@ -895,7 +926,7 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         // moved to their place once the offsets are known
         const bool park = want_parked && kind == SPX_DIGEST_PROMOTED;
         uint8_t* stash = park ? d_out : nullptr;
-        if (!park) SPX_HIP(hipMallocAsync((void**)&stash, total_chars + 64, st));
+        if (!park) SPX_HIP(scr.get((void**)&stash, total_chars + 64));
         const uint64_t groups = (nreads + 63) / 64;
         // the tile: what 64 reads of mean length take (+ 3 %), in steps of 1 KB; a group that needs more goes through it in
         // several (overlapping) tiles
@@ -927,7 +958,6 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         else
             k_digest_unstash<SPX_DIGEST_DNA><<<grid2, 64, 0, st>>>(a, stash);
         SPX_HIP(hipGetLastError());
-        SPX_HIP(hipFreeAsync(stash, st));
     } else {
         const size_t lds = 2 * (size_t)ring + 256;
         const uint32_t grid = (uint32_t)(nreads < cus * 64 ? nreads : cus * 64);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
 
@@ -128,6 +129,21 @@ struct BatchArgs {
 
 }  // namespace spx
 
+namespace spx {
+// The device arrays of an index once more than one handle uses them: spx_index_clone onto the SAME device hands out a
+// second query context -- its own counters, scratch, stream and locks -- over the same (read-only) arrays instead of a
+// copy; the arrays go when the last handle does.
+struct ArrayOwner {
+    int device = 0;
+    void* p[10] = {};
+    ~ArrayOwner() {
+        (void)hipSetDevice(device);
+        for (void* a : p)
+            if (a) (void)hipFree(a);
+    }
+};
+}  // namespace spx
+
 struct spx_index {
     int device = 0;
     uint64_t n = 0, r = 0;
@@ -146,6 +162,13 @@ struct spx_index {
     // bytes of every device array above, in the order of spx::index_arrays() (saved / cloned as they are)
     static constexpr int NARR = 10;
     uint64_t arr_bytes[NARR] = {};
+    std::shared_ptr<spx::ArrayOwner> owner;  // set once the arrays are shared with a same-device clone (else: this handle frees them)
+    // host-buffer queries (spx_query_batch*, spx_digest_*batch, spx_query_text_*) run on a stream of the handle's own, so
+    // that two handles on one device -- the CLI's two workers per device -- overlap one's copies with the other's kernels
+    hipStream_t ctx_stream = nullptr;
+    // the digestion's stream-ordered scratch comes from a pool of the handle's own (the release threshold used to
+    // be set on the device's DEFAULT pool -- a process-wide side effect that outlived the handle); nullptr: default pool
+    hipMemPool_t pool = nullptr;
     spx::DevIndex view{};
     spx::WalkCounters* counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
@@ -247,8 +270,9 @@ int prepare_len_mask(spx_index* ix, int mode, BatchArgs& args);
 int launch_len_expand(spx_index* ix, const BatchArgs& args, hipStream_t stream);
 // long-read batches: the chunked walk (returns SPX_OK and sets *done = false when the batch does not
 // qualify and the plain walk should run)
+// geom_chars (0: total_chars): the characters the batch is expected to hold when total_chars is only an upper bound
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
-                        bool* done);
+                        bool* done, uint64_t geom_chars = 0);
 // spx_text.hip: the values lines of one vector as text (count + scan, then -- the stream's size known -- the digits)
 int launch_text_count(const void* d_vals, int value_bytes, const uint64_t* d_offs, const uint32_t* d_gap, uint64_t nreads,
                       uint64_t* d_line_bytes, uint64_t* d_line_start, void* d_cub, size_t cub_bytes, hipStream_t st);

@@ -1675,8 +1675,9 @@ int run_chunked(spx_index* ix, BatchArgs a, uint64_t bound, hipStream_t stream) 
 // offsets[0] need not be 0): the kernels index the per-character scratch relative to offs[0], which they read
 // from device memory.
 int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars, hipStream_t stream,
-                        bool* done) {
+                        bool* done, uint64_t geom_chars) {
     *done = false;
+    const uint64_t gchars = geom_chars ? geom_chars : total_chars;  // shapes the chunks; total_chars bounds the scratch
     ix->last_chunk_len = ix->last_chunk_bound = 0;
     if (!ix->view.compact || ix->force_lanes_per_wave > 0 || args.nreads == 0) return SPX_OK;
     if (mode == SPX_MODE_PML && args.out_lengths == nullptr) return SPX_OK;  // classification only: the plain walk
@@ -1702,11 +1703,11 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     const uint32_t CK = 1u << CKPT_SHIFT;
     // Every read end cuts one more chunk, so k chunks per lane means total / L + nreads <= k * lanes.
     const uint32_t pref = ix->view.nletters > 16 ? 176 : 640, lo = ix->view.nletters > 16 ? 128 : 512;
-    uint64_t k = (total_chars / lanes + pref / 2) / pref;
+    uint64_t k = (gchars / lanes + pref / 2) / pref;
     if (k < 1) k = 1;
     while (k * lanes <= args.nreads + args.nreads / 8) k++;
     const uint64_t slots = k * lanes - args.nreads - args.nreads / 16;  // full chunks that fit
-    uint64_t L64 = ((total_chars + slots - 1) / slots + CK - 1) / CK * CK;
+    uint64_t L64 = ((gchars + slots - 1) / slots + CK - 1) / CK * CK;
     if (L64 < lo) L64 = lo;
     if (L64 > 1024) L64 = 1024;
     if (ix->chunk_shift > 0) L64 = 1ull << (ix->chunk_shift > 20 ? 20 : ix->chunk_shift);
@@ -1715,7 +1716,7 @@ int launch_walk_chunked(spx_index* ix, int mode, const BatchArgs& args, uint64_t
     const uint32_t L = (uint32_t)L64;
     if (mode_knob != 2) {
         // worth it when the reads alone leave most lanes idle and are long enough to cut
-        if (args.nreads * 2 > lanes || total_chars < args.nreads * (4ull * L)) return SPX_OK;
+        if (args.nreads * 2 > lanes || gchars < args.nreads * (4ull * L)) return SPX_OK;
     }
     const uint64_t bound = total_chars / L + 2 * args.nreads + 1;
     // scratch (grow-only, owned by the index)

@@ -376,6 +376,10 @@ int spx_last_chunk_stats(spx_index *ix, uint64_t out[4]) {
 }
 void *spx_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void spx_host_free(void *p) { free(p); }
+/* (nothing to lock here: "registered" memory is written by memcpy like any other, which is what lets the CPU tier run the
+ * harness's text-straight-into-the-file path) */
+int spx_host_register(void *p, size_t bytes) { (void)bytes; return p ? SPX_OK : SPX_E_ARG; }
+int spx_host_unregister(void *p) { (void)p; return SPX_OK; }
 
 /* ---- digestion -------------------------------------------------------------------------------------------- */
 uint64_t spx_digest_capacity(int kind, uint32_t k, uint64_t total_chars) {

@@ -96,6 +96,37 @@ def test_many_small_super_batches_on_three_workers(on_fake_device, tmp_path, mon
     T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, [], "-P", fastq=True)
 
 
+@pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.02"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.6"},
+                                    {"SPUMONI_MAP_OUTPUT": "0"}])
+def test_output_files_tails_as_memory(on_fake_device, tmp_path, monkeypatch, oracle_mod, regime):
+    """Round 5: the output files' tails are prepared as memory while the index loads (allocated, mapped, registered with the
+    device) and a super-batch's text lands in the file's pages at its place in input order -- no write().  The same bytes as
+    the oracle harness when every tail is mapped (SPUMONI_MAP_MIN=1: also for these tiny files), when the estimate is short
+    and the run crosses into plain writes after a few super-batches (SPUMONI_MAP_FACTOR), when the mapping is not
+    registered and the pool copies the text in (nopin), and with the mechanism off; a fatal read cuts the files where the
+    reference stops although later super-batches are already in the mapping."""
+    T = _cli()
+    for k, v in regime.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0,0")
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 48, list(b"ACGT"), nreads=400)
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    err = r.stderr.decode()
+    if regime.get("SPUMONI_MAP_OUTPUT") == "0":
+        assert "its tail was prepared as memory" not in err
+    else:
+        assert "its tail was prepared as memory" in err, err[-1500:]
+    T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "60"], "-M")
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    T.test_cli_empty_read_is_fatal_after_earlier_reads_were_written(None, tmp_path / "a")
+    T.test_cli_read_empty_after_digestion_is_fatal_in_order(None, tmp_path / "b", oracle_mod)
+    assert not [f for f in os.listdir(tmp_path) if ".partial." in f]
+
+
 @pytest.mark.parametrize("case", sorted(os.listdir(FILES)) if os.path.isdir(FILES) else [])
 def test_cli_reproduces_the_committed_files(on_fake_device, tmp_path, monkeypatch, case):
     """tests/golden/files through the host binary: the harness's output files are the committed ones."""

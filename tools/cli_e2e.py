@@ -46,7 +46,9 @@ for f in os.listdir(d):
 def run(tag, reads, extra_env):
     env = dict(os.environ, **extra_env)
     t0 = time.time()
-    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", reads, "-P", "-c", "-n"],
+    extra = extra_env.pop("E2E_EXTRA", "").split()
+    env = dict(os.environ, **extra_env)
+    r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", reads, "-P", "-c", "-n"] + extra,
                        capture_output=True, env=env)
     dt = time.time() - t0
     err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
@@ -66,7 +68,7 @@ def run(tag, reads, extra_env):
 
 
 run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
-run("flat-layout cache", f"{d}/reads.fa", {})
+run("flat-layout cache (default: SPUMONI_GPUS=0,0 -- two workers, one copy of the index)", f"{d}/reads.fa", {})
 run("flat-layout cache, again", f"{d}/reads.fa", {})
 run("flat-layout cache, SPUMONI_HOST_FORMAT=1 (round 2: values over PCIe, digits on the host)", f"{d}/reads.fa", {"SPUMONI_HOST_FORMAT": "1"})
 os.replace(f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths")
@@ -74,8 +76,16 @@ run("flat-layout cache, text from the device again", f"{d}/reads.fa", {})
 print("   cmp host-formatted against device-formatted .pseudo_lengths:",
       "identical" if subprocess.run(["cmp", f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths"]).returncode == 0 else "DIFFERENT", flush=True)
 os.remove(f"{d}/host_format.pseudo_lengths")
-run("SPUMONI_GPUS=0,0 (two workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0"})
+run("SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0"})
+run("SPUMONI_GPUS=0,0,0 (three workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0,0"})
+for mb in (8, 16, 32, 128):
+    run(f"SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_SUPER_BATCH": str(mb << 20)})
 run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
+run("SPUMONI_REPORT_ONLY=1, again", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
+run("SPUMONI_REPORT_ONLY=1 SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_GPUS": "0"})
+for mb in (8, 16, 32):
+    run(f"SPUMONI_REPORT_ONLY=1 SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_SUPER_BATCH": str(mb << 20)})
+run("-t 8 (a pool of eight)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 8"})
 # ---- CPU: the oracle harness, file to file, one thread (the reference's -t 1 shape) ----
 run("GPU CLI on the CPU sample", f"{d}/sample.fa", {})
 for ext in (".pseudo_lengths", ".report"):
