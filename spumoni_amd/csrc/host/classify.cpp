@@ -587,7 +587,7 @@ enum { F_LENGTHS = 0, F_POINTERS = 1, F_DOCS = 2, F_REPORT = 3, NFILES = 4 };
 }  // namespace
 struct OutputFiles {
     OutFile f[NFILES];  // .pseudo_lengths | .lengths, .pointers, .doc_numbers, .report
-    double prepare_s = 0;
+    double prepare_s = 0, prep_s[3] = {0, 0, 0};  // preparing the tails: in all; fallocate + mmap, page table entries, page-locking
 };
 namespace {
 using Outputs = OutputFiles;
@@ -1079,6 +1079,7 @@ void fill_slot(Pool& pool, const ReadFile& input, const std::vector<ReadFile::Ra
 // Called on a helper thread while the index loads: the page-locked blocks the slots of classify_reads will ask for
 // (per slot: the reads of a super-batch with their offsets and header sizes, the class records, and per output stream
 // its text and its record offsets).
+bool outputs_can_be_mapped(const RunOptions& o);
 static size_t slots_for(size_t nworkers) { return nworkers + 4; }  // one per worker, two being parsed, two being written
 void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
     if (spx_device_count() <= 0) return;
@@ -1099,16 +1100,18 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
         sizes.push_back(reads_guess * 4);        // their header sizes
         if (o.write_report) sizes.push_back(reads_guess * sizeof(spx_class));
         if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
+        // (the streams' record offsets always; their text only when it will not land in the files themselves)
+        const bool text_staged = !outputs_can_be_mapped(o);
         if (!report_only) {  // lengths: "<value> " is 2-4 bytes for most values
-            sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
+            if (text_staged) sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.ms) {  // pointers: up to 13 digits
-            sizes.push_back(chars * 12);
+            if (text_staged) sizes.push_back(chars * 12);
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.use_doc) {
-            sizes.push_back(chars * 3);
+            if (text_staged) sizes.push_back(chars * 3);
             sizes.push_back((reads_guess + 1) * 8);
         }
     }
@@ -1149,86 +1152,119 @@ bool env_is(const char* name, const char* value) {
 }
 }  // namespace
 
-OutputFiles* prepare_outputs(const RunOptions& o, uint64_t reads_file_bytes, uint64_t reads_guess) {
-    OutputFiles* out = new OutputFiles;
+bool outputs_can_be_mapped(const RunOptions& o) {
     // only the path that produces the files' text on the device lands it in the files (SPUMONI_MAP_OUTPUT=0: never)
-    if (o.is_general_text || std::getenv("SPUMONI_HOST_FORMAT") || env_is("SPUMONI_MAP_OUTPUT", "0")) return out;
+    return !(o.is_general_text || std::getenv("SPUMONI_HOST_FORMAT") || env_is("SPUMONI_MAP_OUTPUT", "0"));
+}
+
+// One file's tail as memory: created under a temporary name, `size` bytes allocated (fallocate), mapped, its page table
+// entries made by a few threads, and -- the value streams -- page-locked for the device.
+static void prepare_one(OutputFiles* out, int f, const std::string& final_path, uint64_t est, bool pin) {
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    OutFile& of = out->f[f];
+    of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
+    const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return;
+    register_leftover(of.temp_path);
+    const uint64_t size = (est + 4095) & ~4095ull;
+    void* m = MAP_FAILED;
+    auto t0 = tick();
+    if (::fallocate(fd, 0, 0, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) {  // (a file system that cannot do either: the file is written the ordinary way)
+        if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
+        of.fd = fd;
+        return;
+    }
+    const double s0 = since(t0);
+    t0 = tick();
+    {
+        // the page table entries now, by a few threads, so that nothing faults inside the run
+        const unsigned nt = 4;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([=] {
+                const uint64_t lo = (size / 4096 * t / nt) * 4096, hi = t + 1 == nt ? size : (size / 4096 * (t + 1) / nt) * 4096;
+#ifdef MADV_POPULATE_WRITE
+                if (hi > lo && ::madvise((char*)m + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+                for (uint64_t a = lo; a < hi; a += 4096) {
+                    volatile char* p = (volatile char*)m + a;
+                    *p = *p;
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    const double s1 = since(t0);
+    t0 = tick();
+    of.fd = fd;
+    of.map = (char*)m;
+    of.map_size = size;
+    if (pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) of.pinned = spx_host_register(m, size) == SPX_OK;
+    std::lock_guard<std::mutex> g(g_settle_mu);
+    out->prep_s[0] += s0;
+    out->prep_s[1] += s1;
+    out->prep_s[2] += since(t0);
+}
+
+static uint64_t map_min_bytes() {
+    // (SPUMONI_MAP_MIN / SPUMONI_MAP_FACTOR: tests map the tails of tiny files, and size them short so that a run crosses from
+    // the prepared tail into plain writes)
+    if (const char* e = std::getenv("SPUMONI_MAP_MIN")) return std::strtoull(e, nullptr, 10);
+    return 8u << 20;  // (small files: write() is fine)
+}
+static double map_factor() {
+    if (const char* e = std::getenv("SPUMONI_MAP_FACTOR")) return std::max(0.0, std::atof(e));
+    return 1.0;
+}
+static uint64_t mem_available() {
+    uint64_t avail = ~0ull;
+    std::ifstream mi("/proc/meminfo");
+    std::string key, unit;
+    uint64_t kb;
+    while (mi >> key >> kb >> unit)
+        if (key == "MemAvailable:") avail = kb * 1024;
+    return avail;
+}
+
+// The value streams: sized from the reads file's size alone, so that this can start with the process (nothing of the device
+// is needed before the last step).
+OutputFiles* new_output_files() { return new OutputFiles; }
+
+void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_bytes) {
+    if (!out || !outputs_can_be_mapped(o)) return;
     const auto t0 = std::chrono::steady_clock::now();
     const bool digest = o.use_promotions || o.use_dna_letters;
     // values per input character: every character without digestion; with it about two minimizers per window of
     // w - k + 1 k-mers (k letters each with -a)
     double v = 1.0;
     if (digest) v = std::min(1.0, 2.2 / (double)(o.w - o.k + 2) * (o.use_dna_letters ? (double)o.k : 1.0));
-    double factor = 1.0;
-    if (const char* e = std::getenv("SPUMONI_MAP_FACTOR")) factor = std::max(0.0, std::atof(e));
-    const double fb = (double)reads_file_bytes;
+    const double factor = map_factor(), fb = (double)reads_file_bytes;
     // bytes per value: lengths "<1-3 digits> ", pointers "<up to 13 digits> ", document ids "<1-3 digits> "; + the ">id" lines
-    uint64_t est[NFILES] = {0, 0, 0, 0};
+    uint64_t est[3] = {0, 0, 0};
     const bool report_only = o.report_only && !o.ms && o.write_report;
-    if (!report_only) est[F_LENGTHS] = (uint64_t)(fb * (0.2 + (o.ms ? 3.6 : 2.8) * v) * factor);
-    if (o.ms) est[F_POINTERS] = (uint64_t)(fb * (0.2 + 11.0 * v) * factor);
-    if (o.use_doc) est[F_DOCS] = (uint64_t)(fb * (0.2 + 2.3 * v) * factor);
-    if (o.write_report) est[F_REPORT] = (uint64_t)((double)(reads_guess + 16) * 100.0 * factor) + 256;
+    if (!report_only) est[F_LENGTHS] = (uint64_t)(fb * (0.15 + (o.ms ? 3.4 : 2.6) * v) * factor);
+    if (o.ms) est[F_POINTERS] = (uint64_t)(fb * (0.15 + 10.5 * v) * factor);
+    if (o.use_doc) est[F_DOCS] = (uint64_t)(fb * (0.15 + 2.2 * v) * factor);
     // (never more than a third of what the machine has free: the estimate is an upper-ish bound, not a promise)
-    uint64_t avail = ~0ull;
-    {
-        std::ifstream mi("/proc/meminfo");
-        std::string key;
-        uint64_t kb;
-        std::string unit;
-        while (mi >> key >> kb >> unit)
-            if (key == "MemAvailable:") avail = kb * 1024;
+    if (est[0] + est[1] + est[2] > mem_available() / 3) return;
+    static const char* const ext[3] = {nullptr, ".pointers", ".doc_numbers"};
+    for (int f = 0; f < 3; ++f) {
+        if (est[f] == 0 || est[f] < map_min_bytes()) continue;
+        prepare_one(out, f, o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]), est[f], true);
     }
-    uint64_t want = 0;
-    for (uint64_t e : est) want += e;
-    if (want > avail / 3) return out;
-    static const char* const ext[NFILES] = {nullptr, ".pointers", ".doc_numbers", ".report"};
-    // (SPUMONI_MAP_MIN / SPUMONI_MAP_FACTOR: tests map the tails of tiny files, and size them short so that a run crosses from
-    // the prepared tail into plain writes)
-    uint64_t map_min = 8u << 20;
-    if (const char* e = std::getenv("SPUMONI_MAP_MIN")) map_min = std::strtoull(e, nullptr, 10);
-    for (int f = 0; f < NFILES; ++f) {
-        if (est[f] == 0) continue;
-        if (est[f] < map_min) continue;  // (small files: write() is fine)
-        OutFile& of = out->f[f];
-        const std::string final_path = o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]);
-        of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
-        const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-        if (fd < 0) continue;
-        register_leftover(of.temp_path);
-        const uint64_t size = (est[f] + 4095) & ~4095ull;
-        void* m = MAP_FAILED;
-        if (::fallocate(fd, 0, 0, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) {  // (a file system that cannot do either: the file is written the ordinary way)
-            if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
-            of.fd = fd;
-            continue;
-        }
-        // the page table entries now, by a few threads, so that nothing faults inside the run
-        {
-            const unsigned nt = 4;
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t)
-                th.emplace_back([=] {
-                    const uint64_t lo = (size / 4096 * t / nt) * 4096, hi = t + 1 == nt ? size : (size / 4096 * (t + 1) / nt) * 4096;
-#ifdef MADV_POPULATE_WRITE
-                    if (hi > lo && ::madvise((char*)m + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
-#endif
-                    for (uint64_t a = lo; a < hi; a += 4096) {
-                        volatile char* p = (volatile char*)m + a;
-                        *p = *p;
-                    }
-                });
-            for (auto& x : th) x.join();
-        }
-        of.fd = fd;
-        of.map = (char*)m;
-        of.map_size = size;
-        // the report is written by the host's threads; the value streams by the device
-        if (f != F_REPORT && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) of.pinned = spx_host_register(m, size) == SPX_OK;
-    }
-    out->prepare_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return out;
+    std::lock_guard<std::mutex> g(g_settle_mu);
+    out->prepare_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// The report: its size follows from the number of reads, known once the reads file's lines are found.
+void prepare_report(OutputFiles* out, const RunOptions& o, uint64_t reads_guess) {
+    if (!out || !o.write_report || !outputs_can_be_mapped(o)) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t est = (uint64_t)((double)(reads_guess + 16) * 100.0 * map_factor()) + 256;
+    if (est >= map_min_bytes() && est < mem_available() / 3) prepare_one(out, F_REPORT, o.pattern_file + ".report", est, false);
+    std::lock_guard<std::mutex> g(g_settle_mu);
+    out->prepare_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, OutputFiles* prepared) {
@@ -1461,8 +1497,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
         if (out.f[f].is_open())
             std::fprintf(stderr, "[timing] writer %-15s %.3f s  (%.1f MB; %s)\n", fname[f], write_s[(size_t)f], (double)out.f[f].end / 1e6,
                          out.f[f].map_size ? "its tail was prepared as memory" : "plain writes");
-    std::fprintf(stderr, "[timing] output bytes: %.1f MB went straight into the files' pages, %.1f MB through the writer threads (files prepared in %.3f s while the index loaded)\n",
-                 (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s);
+    std::fprintf(stderr, "[timing] output bytes: %.1f MB went straight into the files' pages, %.1f MB through the writer threads (files prepared in %.3f s beside the index load: allocate + map %.3f, page table entries %.3f, page-locking %.3f s)\n",
+                 (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s, out.prep_s[0], out.prep_s[1], out.prep_s[2]);
     for (size_t d = 0; d < nworkers; ++d)
         std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)  + headers / report %.3f s, waiting for input %.3f s\n", d,
                      dev_busy[d], dev_batches[d], dev_finish[d], dev_wait[d]);

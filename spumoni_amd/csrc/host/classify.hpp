@@ -25,7 +25,7 @@ struct RunOptions {  // SpumoniRunOptions, include/spumoni_main.hpp:233-250
     // ours (additive): devices to use, plain text for the MS length extension, batch size
     std::vector<int> devices{0};
     std::string text_file;
-    size_t super_batch_chars = 64u << 20;
+    size_t super_batch_chars = 32u << 20;  // (round 5: 32 MB -- the pipeline fills sooner; 16 .. 64 MB measure the same to a few percent, profiles/r05_cli_e2e.txt)
     size_t format_threads = 1;  // host threads that turn results into text (-t, or the core count)
     bool report_only = false;   // SPUMONI_REPORT_ONLY=1 with -P -c: <pattern>.pseudo_lengths stays empty (PML only)
 };
@@ -59,7 +59,9 @@ class ReadFile;
 // the ordinary way.  Returns an object without prepared files where that does not apply (general text, SPUMONI_HOST_FORMAT,
 // SPUMONI_MAP_OUTPUT=0, small outputs, a file system that cannot map).
 struct OutputFiles;
-OutputFiles* prepare_outputs(const RunOptions& o, uint64_t reads_file_bytes, uint64_t reads_guess);
+OutputFiles* new_output_files();
+void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_bytes);    // the value streams (from the start)
+void prepare_report(OutputFiles* out, const RunOptions& o, uint64_t reads_guess);          // the report (reads counted)
 size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded = nullptr, OutputFiles* prepared = nullptr);
 // page-locked buffers for the slots of classify_reads, made ahead of time (a helper thread, while the index loads)
 void prepare_pinned_pool(const RunOptions& o, size_t ndev);

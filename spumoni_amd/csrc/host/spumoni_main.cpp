@@ -189,22 +189,24 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     auto start_time = std::chrono::system_clock::now();
     // the reads file is mapped and its lines are indexed on another thread while the index loads
     std::unique_ptr<ReadFile> reads;
-    OutputFiles* outputs = nullptr;
+    OutputFiles* outputs = o.is_general_text ? nullptr : new_output_files();
     std::string reads_err;
+    // ... and the output files' tails are prepared as memory (classify.cpp: prepare_outputs) on a third: the value streams,
+    // sized from the reads file's size, from the very start; the report once the reads are counted
+    std::thread outputs_loader;
+    if (!o.is_general_text)
+        outputs_loader = std::thread([&] {
+            struct stat st;
+            prepare_outputs(outputs, o, ::stat(o.pattern_file.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0);
+        });
     std::thread reads_loader;
     if (!o.is_general_text)
         reads_loader = std::thread([&] {
             try {
                 reads.reset(new ReadFile(o.pattern_file, (unsigned)o.format_threads));
-                // the output files' tails as memory, sized from the reads file (classify.cpp: prepare_outputs), beside the
-                // segmentation below and the index load on the main thread
-                std::thread prep([&] {
-                    const uint64_t nlines = reads->lines();
-                    const bool fastq = reads->first_char() == '@';
-                    outputs = prepare_outputs(o, reads->file_bytes(), fastq ? nlines / 4 : nlines / 2);
-                });
+                std::thread rep([&] { prepare_report(outputs, o, reads->first_char() == '@' ? reads->lines() / 4 : reads->lines() / 2); });
                 reads->precompute_ranges(1000);  // reader.loadBatch(input_file, 1000)   (compute_ms_pml.cpp:903)
-                prep.join();
+                rep.join();
             } catch (const std::exception& e) {
                 reads_err = e.what();
             }
@@ -213,6 +215,7 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     if (!o.is_general_text) pinned_loader = std::thread([&] { prepare_pinned_pool(o, std::max<size_t>(o.devices.size(), 1)); });
     set.load(o);
     if (reads_loader.joinable()) reads_loader.join();
+    if (outputs_loader.joinable()) outputs_loader.join();
     if (pinned_loader.joinable()) pinned_loader.join();
     if (!reads_err.empty()) fatal_error("%s", reads_err.c_str());
     DONE_LOG((std::chrono::system_clock::now() - start_time));
@@ -289,7 +292,7 @@ static int run_main(int argc, char** argv) {
     // (PML only: with -M the lengths are what the report is made from and every stream is written -- the host-formatting
     // path used to leave <pattern>.lengths empty there while the device-text path wrote it)
     if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && !o.ms && std::atoi(t) != 0;
-    // characters of reads per super-batch (64 MB; tests: a few thousand, so that a small input runs as many super-batches
+    // characters of reads per super-batch (32 MB; tests: a few thousand, so that a small input runs as many super-batches
     // through the queue, the workers and the ordered writer)
     if (const char* t = std::getenv("SPUMONI_SUPER_BATCH")) o.super_batch_chars = std::max<size_t>(1000, std::strtoull(t, nullptr, 10));
     // -t: the reference's helper threads walk the index; here the GPU does, and the threads

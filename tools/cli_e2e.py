@@ -76,6 +76,10 @@ run("flat-layout cache, text from the device again", f"{d}/reads.fa", {})
 print("   cmp host-formatted against device-formatted .pseudo_lengths:",
       "identical" if subprocess.run(["cmp", f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths"]).returncode == 0 else "DIFFERENT", flush=True)
 os.remove(f"{d}/host_format.pseudo_lengths")
+run("SPUMONI_MAP_OUTPUT=0 (plain writes: one pwrite stream per file)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "0"})
+run("SPUMONI_MAP_OUTPUT=nopin (tails mapped, not registered: the pool copies the text in)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "nopin"})
+run("SPUMONI_MAP_FACTOR=0.5 (the estimate is short: half the file goes through the writer thread)", f"{d}/reads.fa", {"SPUMONI_MAP_FACTOR": "0.5"})
+run("the default again", f"{d}/reads.fa", {})
 run("SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0"})
 run("SPUMONI_GPUS=0,0,0 (three workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0,0"})
 for mb in (8, 16, 32, 128):
