@@ -1729,11 +1729,11 @@ int spx_index_describe(const spx_index* ix, char* buf, size_t cap) {
     snprintf(buf, cap,
              "{\"layout\": \"%s\", \"n\": %llu, \"r\": %llu, \"flat_runs\": %u, \"letters\": %u, \"compact_rows\": %u, "
              "\"fat_slots\": %llu, \"fat_slots_per_run\": %.4f, \"fat_stride\": %u, \"has_samples\": %d, "
-             "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu}",
+             "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu, \"rows_at\": \"%p\", \"dirrows_at\": \"%p\", \"fat_at\": \"%p\"}",
              SPX_LAYOUT_VERSION, (unsigned long long)ix->n, (unsigned long long)ix->r, v.r, v.nletters, v.compact,
              (unsigned long long)v.nfat, (double)v.nfat / (double)(v.r ? v.r : 1), v.fat_stride,
              (int)ix->has_samples, (int)ix->has_docs, (unsigned long long)ix->n_text,
-             (unsigned long long)(ix->device_bytes + ix->n_text));
+             (unsigned long long)(ix->device_bytes + ix->n_text), (void*)ix->rows, (void*)ix->dirrows, (void*)ix->fat);
     return SPX_OK;
 }
 
