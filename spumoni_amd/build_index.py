@@ -326,6 +326,13 @@ def main(argv=None):
     if a.serialized:
         from spumoni_amd.sdsl_streams import write_thrbv
 
+        #  these files carry upstream's names but not everything upstream's loader trusts: say so every time
+        print("[build_index] WARNING: --serialized writes <prefix>.thrbv.spumoni / .thrbv.ms in a restatement of the sdsl-lite / "
+              "r-index stream layout that is UNVERIFIED against an upstream-built file, and the rank / select support "
+              "structures inside them are placeholders: this package's `spumoni run` rebuilds them and reads the files "
+              "correctly; upstream `spumoni run` would deserialise them without complaint and answer wrongly.  Do not hand "
+              "them to upstream.", file=sys.stderr)
+
         heads = np.maximum(raw.heads.numpy(), 1)
         write_thrbv(prefix + ".thrbv.spumoni", heads, raw.lens.numpy(), raw.thr.numpy())
         write_thrbv(prefix + ".thrbv.ms", heads, raw.lens.numpy(), raw.thr.numpy(), raw.ssa.numpy(), raw.esa.numpy())

@@ -146,7 +146,15 @@ def write_thrbv(path, heads, lens, thr, ssa=None, esa=None):
     for c in range(256):
         Fc.append(acc)
         acc += F[c]
-    out = struct.pack("<Q", 0) + struct.pack("<Q", 256) + struct.pack("<256Q", *Fc)
+    # terminator_position: the BWT position of the terminator -- the start of the run whose head is the terminator (written
+    # as 1 after the rewrite of compute_ms_pml.cpp:470-476; every text byte is >= 2)   (was a constant 0)
+    term_pos, p0 = 0, 0
+    for h, l in zip(heads, lens):
+        if h <= 1:
+            term_pos = p0
+            break
+        p0 += l
+    out = struct.pack("<Q", term_pos) + struct.pack("<Q", 256) + struct.pack("<256Q", *Fc)
     # rle_string: n, R, B, runs (last position of every B-th run), runs_per_letter, run_heads
     B = 2
     out += struct.pack("<QQQ", n, R, B)

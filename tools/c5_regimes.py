@@ -74,29 +74,32 @@ if os.environ.get("C5_REGIMES_PART_A"):
 # ---- B: the index laid out again, under different circumstances ----
 class DevArray:  # a library-owned device array as a torch tensor (no copy)
     def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes // 16, 2), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
 def probe(ix):
-    """independent random 16-byte reads over each of the three big arrays (torch's gather): does the memory system itself answer
-    differently where the walk does?"""
-    d = ix.describe()
-    out = []
-    r = int(d["flat_runs"])
-    for name, nbytes in (("rows_at", r * 32), ("dirrows_at", r * 32), ("fat_at", int(d["fat_slots"]) * int(d["fat_stride"]))):
-        t = torch.as_tensor(DevArray(int(d[name], 16), nbytes), device="cuda")
-        idx = torch.randint(0, t.shape[0], (1 << 26,), device="cuda")
-        acc = t[idx].sum()  # warm-up
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            acc = acc + t[idx].sum()
-        e1.record()
-        torch.cuda.synchronize()
-        out.append(f"{name[:-3]} {3 * (1 << 26) / (e0.elapsed_time(e1) * 1e-3) / 1e9:.1f}")
-        del t, idx
-    return "torch gather G/s: " + ", ".join(out)
+    """independent random 8-byte reads, one per 16-byte record, over each of the three big arrays (torch.take): does the memory
+    system itself answer differently where the walk does?"""
+    try:
+        d = ix.describe()
+        out = []
+        r = int(d["flat_runs"])
+        for name, nbytes in (("rows_at", r * 32), ("dirrows_at", r * 32), ("fat_at", int(d["fat_slots"]) * int(d["fat_stride"]))):
+            t = torch.as_tensor(DevArray(int(d[name], 16), nbytes), device="cuda")
+            idx = torch.randint(0, t.shape[0] // 2, (1 << 25,), device="cuda") * 2
+            acc = torch.take(t, idx).sum()  # warm-up
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                acc = acc + torch.take(t, idx).sum()
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(f"{name[:-3]} {4 * (1 << 25) / (e0.elapsed_time(e1) * 1e-3) / 1e9:.1f}")
+            del t, idx
+        return "torch.take G/s: " + ", ".join(out)
+    except Exception as e:
+        return "probe failed: " + str(e).splitlines()[0][:100]
 
 
 def lay_out(tag, before=None, free_raw_first=False, hold_gb=0):
