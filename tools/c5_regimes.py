@@ -78,6 +78,8 @@ class DevArray:  # a library-owned device array as a torch tensor (no copy)
 
 
 def probe(ix):
+    if os.environ.get("C5_REGIMES_HOLDS"):
+        return ""
     """independent random 8-byte reads, one per 16-byte record, over each of the three big arrays (torch.take): does the memory
     system itself answer differently where the walk does?"""
     try:
@@ -137,6 +139,10 @@ if os.environ.get("C5_REGIMES_PART_A"):
     lay_out("again, at once")
     lay_out("after 60 s idle", before=lambda: time.sleep(60))
     lay_out("after a 100 GB block was allocated, written and freed", before=big_block)
+if os.environ.get("C5_REGIMES_HOLDS"):  # (tools/c5_regimes_pmc.sh: the two regimes, nothing else)
+    for gb in [int(x) for x in os.environ["C5_REGIMES_HOLDS"].split(",")]:
+        lay_out(f"{gb} GB held during the layout", hold_gb=gb)
+    sys.exit(0)
 for gb in (0, 4, 0, 12, 1, 24, 0, 2):
     lay_out(f"{gb} GB held during the layout", hold_gb=gb)
 lay_out("raw arrays freed before the batch", free_raw_first=True)
