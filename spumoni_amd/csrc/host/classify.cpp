@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <array>
 #include <cctype>
 #include <chrono>
 #include <cstdlib>
@@ -1080,7 +1081,10 @@ void fill_slot(Pool& pool, const ReadFile& input, const std::vector<ReadFile::Ra
 // (per slot: the reads of a super-batch with their offsets and header sizes, the class records, and per output stream
 // its text and its record offsets).
 bool outputs_can_be_mapped(const RunOptions& o);
-static size_t slots_for(size_t nworkers) { return nworkers + 4; }  // one per worker, two being parsed, two being written
+// feeders: two for a device's two workers, one more per further device (eight at most): SURVEY 8(e)'s "one feeder thread group
+// per GPU" -- the groups share the pool, whose size follows the devices as well (spumoni_main.cpp)
+static size_t feeders_for(size_t nworkers) { return std::max<size_t>(2, std::min<size_t>(8, nworkers / 2 + 1)); }
+static size_t slots_for(size_t nworkers) { return nworkers + feeders_for(nworkers) + 2; }  // one per worker, one per feeder, two being written
 void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
     if (spx_device_count() <= 0) return;
     // sized from the reads file, not from the super-batch limit alone: a small file needs small blocks and few
@@ -1294,7 +1298,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     // independent (compute_ms_pml.cpp:907-938: nothing is carried from one read to the next), so a slower or busier
     // device simply takes fewer super-batches.  The reference's loop this replaces: compute_ms_pml.cpp:890-1024.
     const size_t nworkers = set.ix.size();
-    constexpr int NFEED = 2;
+    const int NFEED = (int)feeders_for(nworkers);
     const int NSLOTS = (int)slots_for(nworkers);
     Pool pool(std::max<size_t>(1, o.format_threads) - 1);
     // (the slots outlive the call on purpose: unlocking their page-locked buffers takes a few tenths of a
@@ -1440,7 +1444,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     std::atomic<bool> input_done{false};  // (set without the lock by a feeder whose super-batch ends in a fatal read: the other
                                           // feeder may be waiting for a slot with the lock held)
     uint64_t next_seq = 0;
-    double seg_s = 0, parse_s[NFEED][2] = {};
+    double seg_s = 0;
+    std::vector<std::array<double, 2>> parse_s((size_t)NFEED, std::array<double, 2>{0.0, 0.0});
     auto feeder = [&](int fi) {
         std::vector<ReadFile::Range> ranges;
         for (;;) {
@@ -1468,7 +1473,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                 seg_s += since(t0);
             }
             Slot& s = slots[(size_t)i];
-            fill_slot(pool, input, ranges, s, parse_s[fi]);
+            fill_slot(pool, input, ranges, s, parse_s[(size_t)fi].data());
             if (s.deferred) input_done = true;  // nothing behind a malformed / empty read is part of the run
             const bool last = s.last;
             const uint64_t seq = s.seq;
@@ -1489,7 +1494,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
     double p0 = 0, p1 = 0;
-    for (int fi = 0; fi < NFEED; ++fi) p0 += parse_s[fi][0], p1 += parse_s[fi][1];
+    for (int fi = 0; fi < NFEED; ++fi) p0 += parse_s[(size_t)fi][0], p1 += parse_s[(size_t)fi][1];
     std::fprintf(stderr, "[timing] %-22s %.3f s  (%d feeders on a pool of %zu: segmentation %.3f  scan %.3f  copy %.3f s)\n", "segment+parse",
                  seg_s + p0 + p1, NFEED, pool.size(), seg_s, p0, p1);
     static const char* const fname[NFILES] = {"lengths", "pointers", "doc_numbers", "report"};
