@@ -247,7 +247,8 @@ class Index:
         return lib().spx_index_source_tag(self._h).decode()
 
     def clone(self, device: int) -> "Index":
-        """A copy of this index on `device` (device-to-device, no re-flattening)."""
+        """A copy of this index on `device` (device-to-device, no re-flattening); onto the SAME device: a second query context --
+        scratch, counters and stream of its own -- over the same arrays (nothing is copied)."""
         h = lib().spx_index_clone(self._h, device)
         if not h:
             raise SpxError(lib().spx_last_error().decode())

@@ -1502,7 +1502,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
         if (out.f[f].is_open())
             std::fprintf(stderr, "[timing] writer %-15s %.3f s  (%.1f MB; %s)\n", fname[f], write_s[(size_t)f], (double)out.f[f].end / 1e6,
                          out.f[f].map_size ? "its tail was prepared as memory" : "plain writes");
-    std::fprintf(stderr, "[timing] output bytes: %.1f MB went straight into the files' pages, %.1f MB through the writer threads (files prepared in %.3f s beside the index load: allocate + map %.3f, page table entries %.3f, page-locking %.3f s)\n",
+    std::fprintf(stderr, "[timing] output bytes: %.3f MB went straight into the files' pages, %.3f MB through the writer threads (files prepared in %.3f s beside the index load: allocate + map %.3f, page table entries %.3f, page-locking %.3f s)\n",
                  (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s, out.prep_s[0], out.prep_s[1], out.prep_s[2]);
     for (size_t d = 0; d < nworkers; ++d)
         std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)  + headers / report %.3f s, waiting for input %.3f s\n", d,

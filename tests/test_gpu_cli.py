@@ -469,6 +469,33 @@ def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch
     assert os.path.getsize(str(tmp_path / "gpu" / "fatal.fa") + ".pseudo_lengths") == 0
 
 
+@pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin"}])
+def test_cli_output_tails_as_memory_on_the_device(built, tmp_path, monkeypatch, regime):
+    """Round 5, on the device: the output files' tails prepared as memory and registered with HIP (spx_host_register on a
+    MAP_SHARED mapping of the file), the text of every super-batch copied by the device into the file's pages at its place in
+    input order -- for these small files too (SPUMONI_MAP_MIN=1); an estimate that is short, so that later super-batches go
+    through the slot's buffer and the file's writer thread; mapped without registration (the pool copies the text in).  PML
+    and MS with documents and report on two workers and some twenty super-batches: the oracle harness's bytes; the log says
+    that the bytes went where the regime says."""
+    for k, v in regime.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    ref, prefix, seqs, offs, rng = _setup(tmp_path, 49, list(b"ACGT"), nreads=400)
+    for mode, extra in (("-P", ["-c", "-d", "-w", "50"]), ("-M", ["-c", "-d", "-w", "60"])):
+        r = _run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, extra, mode)
+        err = r.stderr.decode()
+        assert "its tail was prepared as memory" in err, err[-1500:]
+        line = [ln for ln in err.splitlines() if "output bytes:" in ln][0]
+        direct = float(line.split("output bytes:")[1].split("MB")[0])
+        staged = float(line.split("pages,")[1].split("MB")[0])
+        if "SPUMONI_MAP_FACTOR" in regime:
+            assert direct > 0 and staged > 0, line
+        else:
+            assert direct > 0 and staged == 0, line
+    assert not [f for f in os.listdir(tmp_path / "gpu") if ".partial." in f]
+
+
 def test_cli_four_workers_on_many_small_super_batches(built, tmp_path, monkeypatch):
     """SPUMONI_GPUS=0,0,0,0: four workers on one device -- one copy of the index, four query contexts --
     pulling some forty super-batches of 1500 characters from one queue, the ordered writer putting them back in
