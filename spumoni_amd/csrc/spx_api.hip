@@ -1726,14 +1726,19 @@ int spx_index_describe(const spx_index* ix, char* buf, size_t cap) {
         return SPX_E_ARG;
     }
     const DevIndex& v = ix->view;
+    // (SPX_DESCRIBE_ADDRESSES: also where the three big arrays lie -- tools/c5_regimes.py; not part of the description proper,
+    // which is equal for an index and its copy)
+    char where[160] = "";
+    if (getenv("SPX_DESCRIBE_ADDRESSES"))
+        snprintf(where, sizeof where, ", \"rows_at\": \"%p\", \"dirrows_at\": \"%p\", \"fat_at\": \"%p\"", (void*)ix->rows, (void*)ix->dirrows, (void*)ix->fat);
     snprintf(buf, cap,
              "{\"layout\": \"%s\", \"n\": %llu, \"r\": %llu, \"flat_runs\": %u, \"letters\": %u, \"compact_rows\": %u, "
              "\"fat_slots\": %llu, \"fat_slots_per_run\": %.4f, \"fat_stride\": %u, \"has_samples\": %d, "
-             "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu, \"rows_at\": \"%p\", \"dirrows_at\": \"%p\", \"fat_at\": \"%p\"}",
+             "\"has_docs\": %d, \"n_text\": %llu, \"device_bytes\": %llu%s}",
              SPX_LAYOUT_VERSION, (unsigned long long)ix->n, (unsigned long long)ix->r, v.r, v.nletters, v.compact,
              (unsigned long long)v.nfat, (double)v.nfat / (double)(v.r ? v.r : 1), v.fat_stride,
              (int)ix->has_samples, (int)ix->has_docs, (unsigned long long)ix->n_text,
-             (unsigned long long)(ix->device_bytes + ix->n_text), (void*)ix->rows, (void*)ix->dirrows, (void*)ix->fat);
+             (unsigned long long)(ix->device_bytes + ix->n_text), where);
     return SPX_OK;
 }
 

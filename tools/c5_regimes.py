@@ -8,6 +8,7 @@ box were cleared).  Two questions, one process:
      batch time.
     python tools/c5_regimes.py [runs=2000000000]"""
 import os, subprocess, sys, time
+os.environ["SPX_DESCRIBE_ADDRESSES"] = "1"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spumoni_amd import capi, synth
