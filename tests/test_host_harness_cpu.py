@@ -222,6 +222,19 @@ def test_cli_differential_fuzz_against_the_oracle_harness(on_fake_device, tmp_pa
     assert "bad 0" in r.stdout
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.5"}])
+def test_cli_differential_fuzz_with_the_output_tails_as_memory(on_fake_device, tmp_path, regime):
+    """The same fuzz, thirty other seeds, with the round-5 drain in each of its regimes (the files' tails mapped + registered,
+    an estimate that runs out mid-run, mapped without registration): fatal reads must still cut every file where the
+    reference stops.  (6 000 further seeds, ASan and TSan builds: DESIGN.md 6.)"""
+    env = dict(os.environ, FAKE_DEVICE_DIR=on_fake_device, CLI_FUZZ_DIR=str(tmp_path / "fuzz"), **regime)
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "cli_fuzz_cpu.py"), "30", "500"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "bad 0" in r.stdout
+
+
 def test_general_text_mode(on_fake_device, tmp_path):
     """`run -g -n` (classify_general_reads_pml / _ms, compute_ms_pml.cpp:1219-1297) through the ASan build against the oracle
     harness: tests/test_gpu_cli.py::_general_text_case (bytes >= 128, a NUL, lower case, empty reads, trailing text,
