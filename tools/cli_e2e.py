@@ -95,6 +95,46 @@ run("SPUMONI_REPORT_ONLY=1 SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUM
 for mb in (8, 16, 32):
     run(f"SPUMONI_REPORT_ONLY=1 SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_SUPER_BATCH": str(mb << 20)})
 run("-t 8 (a pool of eight)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 8"})
+# ---- MS mode: three output files side by side (lengths, pointers, report) ----
+if os.environ.get("E2E_MS", "1") != "0":
+    dm = d + "/ms"; os.makedirs(dm, exist_ok=True)
+    raw_ms = synth.index_from_text(torch.from_numpy(text).cuda(), with_samples=True).cpu()
+    open(f"{dm}/ref.fa", "w").write(">x\n")
+    raw_ms.write_raw_files(f"{dm}/ref.fa")
+    text.tofile(f"{dm}/ref.fa.rawtext")
+    write_null_db(f"{dm}/ref.fa.msnulldb", 8.0, [5, 9, 9, 9])
+    n_ms = min(nreads, int(os.environ.get("E2E_MS_READS", "1000000")))
+    write_fasta(f"{dm}/reads.fa", 0, n_ms)
+
+    def run_ms(tag, extra_env):
+        env = dict(os.environ, SPUMONI_TEXT=f"{dm}/ref.fa.rawtext", **extra_env)
+        t0 = time.time()
+        r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{dm}/ref", "-p", f"{dm}/reads.fa", "-M", "-c", "-n"], capture_output=True, env=env)
+        dt = time.time() - t0
+        err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
+        assert r.returncode == 0, err
+        import re
+        secs = [float(x) for x in re.findall(r"done\.\s+\(([0-9.]+) sec\)", err)]
+        load_s, proc_s = (secs + [0, 0])[:2]
+        sizes = {e: os.path.getsize(f"{dm}/reads.fa" + e) / 1e6 for e in (".lengths", ".pointers", ".report")}
+        print(f"== -M -c -n, {n_ms} reads, {tag}: {dt:.2f}s wall; loading the index {load_s:.3f}s, processing the reads {proc_s:.3f}s = "
+              f"{n_ms / max(proc_s, 1e-9) / 1e6:.2f} M reads/s (lengths {sizes['.lengths']:.0f} MB, pointers {sizes['.pointers']:.0f} MB, report {sizes['.report']:.0f} MB)")
+        for l in err.splitlines():
+            if "[timing]" in l:
+                print("   ", l.strip())
+        sys.stdout.flush()
+
+    run_ms("SPUMONI_CACHE=write", {"SPUMONI_CACHE": "write"})
+    run_ms("flat-layout cache", {})
+    for e in (".lengths", ".pointers", ".report"):
+        os.replace(f"{dm}/reads.fa{e}", f"{dm}/mapped{e}")
+    run_ms("SPUMONI_MAP_OUTPUT=0 (plain writes, one writer thread per file)", {"SPUMONI_MAP_OUTPUT": "0"})
+    for e in (".lengths", ".pointers", ".report"):
+        same = subprocess.run(["cmp", f"{dm}/reads.fa{e}", f"{dm}/mapped{e}"]).returncode == 0
+        print(f"   cmp {e} (files' tails as memory against plain writes): {'identical' if same else 'DIFFERENT'}", flush=True)
+    import shutil
+    shutil.rmtree(dm)
+
 # ---- CPU: the oracle harness, file to file, one thread (the reference's -t 1 shape) ----
 run("GPU CLI on the CPU sample", f"{d}/sample.fa", {})
 for ext in (".pseudo_lengths", ".report"):
