@@ -257,6 +257,7 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
               o.ms ? "lengths" : "pseudo_lengths");
     std::cout << std::endl;
     remove_leftovers();  // (a large output of an earlier run, moved aside when its name was taken: gone before we are)
+    if (std::getenv("SPX_FREE_TRACE")) std::fprintf(stderr, "[spumoni] run_spumoni returns\n");
     return 0;
 }
 
@@ -382,7 +383,11 @@ int main(int argc, char** argv) {
         if (std::strcmp(argv[1], "build") == 0)
             fatal_error("`spumoni build` is not part of the MI355X run-path package: build the index with the\n"
                         "       reference (keep the raw files with -k) and query it here.");
-        if (std::strcmp(argv[1], "run") == 0) return run_main(argc - 1, argv + 1);
+        if (std::strcmp(argv[1], "run") == 0) {
+            const int rc = run_main(argc - 1, argv + 1);
+            if (std::getenv("SPX_FREE_TRACE")) std::fprintf(stderr, "[spumoni] main returns %d\n", rc);
+            return rc;
+        }
     }
     return spumoni_usage();
 }

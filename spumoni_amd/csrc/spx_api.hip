@@ -110,6 +110,9 @@ int spx_device_count(void) { return usable_devices(); }
 
 void spx_index_free(spx_index* ix) {
     if (!ix) return;
+    static const bool trace = getenv("SPX_FREE_TRACE") != nullptr;
+#define SPX_FT(what) do { if (trace) fprintf(stderr, "[spx] free %p: %s\n", (void*)ix, what); } while (0)
+    SPX_FT("begin");
     (void)hipSetDevice(ix->device);
     if (ix->owner) {
         ix->owner.reset();  // shared with same-device clones: the last handle frees the arrays
@@ -119,12 +122,10 @@ void spx_index_free(spx_index* ix) {
         for (void** a : arr)
             if (*a) (void)hipFree(*a);
     }
+    SPX_FT("arrays released");
     if (ix->counters) (void)hipFree(ix->counters);
     if (ix->ctx_stream) (void)hipStreamDestroy(ix->ctx_stream);
-    if (ix->pool) {
-        (void)hipDeviceSynchronize();  // (stream-ordered frees into the pool are behind us)
-        (void)hipMemPoolDestroy(ix->pool);
-    }
+    SPX_FT("stream destroyed");
     for (auto& st : ix->pipe_s)
         if (st) (void)hipStreamDestroy(st);
     for (int c = 0; c < spx_index::PIPE_CHUNKS; ++c) {
@@ -135,9 +136,14 @@ void spx_index_free(spx_index* ix) {
         if (sc.p) (void)hipFree(sc.p);
     for (auto& sc : ix->chunk_scr)
         if (sc.p) (void)hipFree(sc.p);
+    for (auto& sc : ix->digest_scr)
+        if (sc.p) (void)hipFree(sc.p);
+    if (ix->ev_dig) (void)hipEventDestroy(ix->ev_dig);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     if (ix->ev_done) (void)hipEventDestroy(ix->ev_done);
+    SPX_FT("done");
+#undef SPX_FT
     delete ix;
 }
 
@@ -181,26 +187,7 @@ static int init_runtime(spx_index* ix) {
     SPX_HIP(hipEventCreate(&ix->ev0));
     SPX_HIP(hipEventCreate(&ix->ev1));
     SPX_HIP(hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming));
-    {
-        // The stream-ordered scratch of the digestion (the parked bytes, the scans' workspace) comes from a pool of the
-        // handle's own.  A pool by default hands freed memory back to the system at the next synchronisation -- and maps it
-        // again at the next call: tens of milliseconds for a 2 GB block, on and off (a 2 ms digestion was seen to take
-        // 37-71 ms in whole runs of tools/digest_bench.py) -- so this one keeps up to 4 GB of what it has been given; it goes
-        // with the handle (round 4 set the threshold on the device's default pool, for the whole process and for good).
-        hipMemPoolProps props;
-        memset(&props, 0, sizeof props);
-        props.allocType = hipMemAllocationTypePinned;
-        props.handleTypes = hipMemHandleTypeNone;
-        props.location.type = hipMemLocationTypeDevice;
-        props.location.id = ix->device;
-        if (hipMemPoolCreate(&ix->pool, &props) == hipSuccess && ix->pool) {
-            uint64_t keep = 4ull << 30;  // (up to 4 GB: a batch's scratch, not what a one-off giant call asked for)
-            (void)hipMemPoolSetAttribute(ix->pool, hipMemPoolAttrReleaseThreshold, &keep);
-        } else {
-            ix->pool = nullptr;  // (the default pool then, with its default threshold: correct, slower)
-        }
-        (void)hipGetLastError();
-    }
+    SPX_HIP(hipEventCreateWithFlags(&ix->ev_dig, hipEventDisableTiming));
     SPX_HIP(hipDeviceSynchronize());
     return SPX_OK;
 }

@@ -738,33 +738,31 @@ __global__ void k_zero_tail(const uint64_t* out_offs, uint64_t nreads, uint8_t* 
 
 }  // namespace
 
-// Stream-ordered scratch that is given back on every way out of launch_digest (an error between the
-// allocations and the frees used to leak up to seven blocks per call).
+// The digestion's scratch: grow-only device buffers owned by the index (spx_index::digest_scr), like the chunked walk's.
+// (Round 4 took them from the stream-ordered allocator, which leaked them on every early return -- ADVICE r4 -- and needed a
+// release threshold on the device's default pool, a process-wide side effect; a pool of the handle's own was tried first and
+// hipMemPoolDestroy hung at exit once page-locked file mappings were in play: profiles/r05_cli_e2e_m_hang.txt.  Plain buffers
+// have neither problem.)  Calls on one handle are enqueued under its mutex; a call on another stream than the one before
+// waits for it (ev_dig), so the buffers are never shared by two calls in flight.
 namespace {
-struct AsyncScratch {
-    hipStream_t st;
-    hipMemPool_t pool;
-    void* p[12] = {};
+struct DigestScratch {
+    spx_index* ix;
     int n = 0;
-    AsyncScratch(hipStream_t s, hipMemPool_t pl) : st(s), pool(pl) {}
-    AsyncScratch(const AsyncScratch&) = delete;
-    AsyncScratch& operator=(const AsyncScratch&) = delete;
+    explicit DigestScratch(spx_index* i) : ix(i) {}
     hipError_t get(void** out, size_t bytes) {
-        if (n >= 12) return hipErrorOutOfMemory;
-        const hipError_t e = pool ? hipMallocFromPoolAsync(out, bytes ? bytes : 16, pool, st) : hipMallocAsync(out, bytes ? bytes : 16, st);
-        if (e == hipSuccess) p[n++] = *out;
-        return e;
-    }
-    void release_now(void* q) {  // freed in stream order right away (and not again by the destructor)
-        for (int i = 0; i < n; ++i)
-            if (p[i] == q) {
-                (void)hipFreeAsync(q, st);
-                p[i] = nullptr;
-            }
-    }
-    ~AsyncScratch() {
-        for (int i = 0; i < n; ++i)
-            if (p[i]) (void)hipFreeAsync(p[i], st);
+        if (n >= spx_index::NDIGSCR) return hipErrorOutOfMemory;
+        spx_index::Scratch& sc = ix->digest_scr[n++];
+        if (sc.cap < bytes) {
+            if (sc.p) (void)hipFree(sc.p);
+            sc.p = nullptr;
+            sc.cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            const hipError_t e = hipMalloc(&sc.p, want);
+            if (e != hipSuccess) return e;
+            sc.cap = want;
+        }
+        *out = sc.p;
+        return hipSuccess;
     }
 };
 }  // namespace
@@ -822,7 +820,18 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     a.counts = d_out_offs;
     a.out_offs = d_out_offs;
     a.out = d_out;
-    AsyncScratch scr(st, ix->pool);
+    DigestScratch scr(ix);
+    if (ix->dig_used && ix->dig_stream != st) SPX_HIP(hipStreamWaitEvent(st, ix->ev_dig, 0));
+    struct Done {  // whatever way out: the next call on another stream waits for what this one enqueued
+        spx_index* ix;
+        hipStream_t st;
+        ~Done() {
+            if (hipEventRecord(ix->ev_dig, st) == hipSuccess) {
+                ix->dig_used = true;
+                ix->dig_stream = st;
+            }
+        }
+    } done{ix, st};
     SPX_HIP(hipMemsetAsync(d_out_offs, 0, 8, st));
     if (nreads == 0) {
         k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, 0, d_out);
@@ -835,13 +844,26 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
     if (ix->force_digest_kernel == 1) lanes = a.wsz <= 8;
     if (ix->force_digest_kernel == 2) lanes = false;
     const uint64_t cus = (uint64_t)(ix->num_cus > 0 ? ix->num_cus : 256);
+    // (the scans' workspace: one buffer of its own, the last slot -- the scans of a call run one after the other on the stream)
+    auto scan_tmp = [&](void** out, size_t bytes) -> hipError_t {
+        spx_index::Scratch& sc = ix->digest_scr[spx_index::NDIGSCR - 1];
+        if (sc.cap < bytes) {
+            if (sc.p) (void)hipFree(sc.p);
+            sc.p = nullptr;
+            sc.cap = 0;
+            const hipError_t e = hipMalloc(&sc.p, bytes + 4096);
+            if (e != hipSuccess) return e;
+            sc.cap = bytes + 4096;
+        }
+        *out = sc.p;
+        return hipSuccess;
+    };
     auto scan_counts = [&]() -> int {  // counts -> offsets, in place
         size_t tmp_bytes = 0;
         SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
         void* tmp = nullptr;
-        SPX_HIP(scr.get(&tmp, tmp_bytes));
+        SPX_HIP(scan_tmp(&tmp, tmp_bytes));
         SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d_out_offs, d_out_offs, nreads + 1, st));
-        scr.release_now(tmp);
         return SPX_OK;
     };
     // long reads of the default shape: a lane per chunk of 240 characters (k_digest_chunks)
@@ -869,12 +891,11 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
                 SPX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, v, v, count, st));
             else
                 SPX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, v, v, count, st));
-            SPX_HIP(scr.get(&tmp, tmp_bytes));
+            SPX_HIP(scan_tmp(&tmp, tmp_bytes));
             if (inclusive)
                 SPX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, v, v, count, st));
             else
                 SPX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, v, v, count, st));
-            scr.release_now(tmp);
             return SPX_OK;
         };
         const unsigned gq = (unsigned)((nreads + 1 + 255) / 256), gc = (unsigned)((bound + 255) / 256);
@@ -916,7 +937,6 @@ int launch_digest(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t
         aw.out = d_out;
         k_digest_wave<1><<<gridw, 64, lds, st>>>(aw);
         SPX_HIP(hipGetLastError());
-        // (the scratch goes back when `scr` does: in stream order, behind the kernels above)
         k_zero_tail<<<1, 64, 0, st>>>(d_out_offs, nreads, d_out);
         SPX_HIP(hipGetLastError());
         return SPX_OK;

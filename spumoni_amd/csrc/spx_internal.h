@@ -166,9 +166,11 @@ struct spx_index {
     // host-buffer queries (spx_query_batch*, spx_digest_*batch, spx_query_text_*) run on a stream of the handle's own, so
     // that two handles on one device -- the CLI's two workers per device -- overlap one's copies with the other's kernels
     hipStream_t ctx_stream = nullptr;
-    // the digestion's stream-ordered scratch comes from a pool of the handle's own (the release threshold used to
-    // be set on the device's DEFAULT pool -- a process-wide side effect that outlived the handle); nullptr: default pool
-    hipMemPool_t pool = nullptr;
+    // the digestion's scratch (spx_digest.hip: grow-only, under mu), the stream its last call ran on and what that call enqueued
+    static constexpr int NDIGSCR = 9;
+    hipEvent_t ev_dig = nullptr;
+    hipStream_t dig_stream = nullptr;
+    bool dig_used = false;
     spx::DevIndex view{};
     spx::WalkCounters* counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
@@ -193,7 +195,7 @@ struct spx_index {
     struct Scratch {
         void* p = nullptr;
         size_t cap = 0;
-    } scratch[20], chunk_scr[9];  // host-buffer queries (8..19: text output); chunked walks and the length bits (under mu)
+    } scratch[20], chunk_scr[9], digest_scr[NDIGSCR];  // host-buffer queries (8..19: text output); chunked walks and the length bits (under mu)
     // spx_query_text_begin -> spx_query_text_fetch: the streams' sizes and where they wait on the device
     uint64_t text_bytes[3] = {0, 0, 0};
     uint64_t text_nreads = 0;

@@ -494,6 +494,13 @@ def test_cli_output_tails_as_memory_on_the_device(built, tmp_path, monkeypatch, 
         else:
             assert direct > 0 and staged == 0, line
     assert not [f for f in os.listdir(tmp_path / "gpu") if ".partial." in f]
+    # ... and with the reads digested on the device first (-m, -a): the place of a super-batch's text is known only after the
+    # digestion; the process must also LEAVE (profiles/r05_cli_e2e_m_hang.txt: a memory pool's destruction once hung here)
+    import oracle
+    for digest, kw in (("m", ()), ("a", (2, 2))):
+        sub = tmp_path / ("dig_" + digest)
+        sub.mkdir()
+        test_cli_with_minimizer_digestion(None, sub, oracle, digest, kw)
 
 
 def test_cli_four_workers_on_many_small_super_batches(built, tmp_path, monkeypatch):

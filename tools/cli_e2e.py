@@ -74,27 +74,29 @@ def run(tag, reads, extra_env):
 
 run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
 run("flat-layout cache (default: SPUMONI_GPUS=0,0 -- two workers, one copy of the index)", f"{d}/reads.fa", {})
+quick = os.environ.get("E2E_QUICK") is not None  # (only the first two runs of the PML block)
 run("flat-layout cache, again", f"{d}/reads.fa", {})
-run("flat-layout cache, SPUMONI_HOST_FORMAT=1 (round 2: values over PCIe, digits on the host)", f"{d}/reads.fa", {"SPUMONI_HOST_FORMAT": "1"})
-os.replace(f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths")
-run("flat-layout cache, text from the device again", f"{d}/reads.fa", {})
-print("   cmp host-formatted against device-formatted .pseudo_lengths:",
-      "identical" if subprocess.run(["cmp", f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths"]).returncode == 0 else "DIFFERENT", flush=True)
-os.remove(f"{d}/host_format.pseudo_lengths")
-run("SPUMONI_MAP_OUTPUT=0 (plain writes: one pwrite stream per file)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "0"})
-run("SPUMONI_MAP_OUTPUT=nopin (tails mapped, not registered: the pool copies the text in)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "nopin"})
-run("SPUMONI_MAP_FACTOR=0.5 (the estimate is short: half the file goes through the writer thread)", f"{d}/reads.fa", {"SPUMONI_MAP_FACTOR": "0.5"})
-run("the default again", f"{d}/reads.fa", {})
-run("SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0"})
-run("SPUMONI_GPUS=0,0,0 (three workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0,0"})
-for mb in (8, 16, 32, 128):
-    run(f"SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_SUPER_BATCH": str(mb << 20)})
-run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
-run("SPUMONI_REPORT_ONLY=1, again", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
-run("SPUMONI_REPORT_ONLY=1 SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_GPUS": "0"})
-for mb in (8, 16, 32):
-    run(f"SPUMONI_REPORT_ONLY=1 SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_SUPER_BATCH": str(mb << 20)})
-run("-t 8 (a pool of eight)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 8"})
+if not quick:
+    run("flat-layout cache, SPUMONI_HOST_FORMAT=1 (round 2: values over PCIe, digits on the host)", f"{d}/reads.fa", {"SPUMONI_HOST_FORMAT": "1"})
+    os.replace(f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths")
+    run("flat-layout cache, text from the device again", f"{d}/reads.fa", {})
+    print("   cmp host-formatted against device-formatted .pseudo_lengths:",
+          "identical" if subprocess.run(["cmp", f"{d}/reads.fa.pseudo_lengths", f"{d}/host_format.pseudo_lengths"]).returncode == 0 else "DIFFERENT", flush=True)
+    os.remove(f"{d}/host_format.pseudo_lengths")
+    run("SPUMONI_MAP_OUTPUT=0 (plain writes: one pwrite stream per file)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "0"})
+    run("SPUMONI_MAP_OUTPUT=nopin (tails mapped, not registered: the pool copies the text in)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "nopin"})
+    run("SPUMONI_MAP_FACTOR=0.5 (the estimate is short: half the file goes through the writer thread)", f"{d}/reads.fa", {"SPUMONI_MAP_FACTOR": "0.5"})
+    run("the default again", f"{d}/reads.fa", {})
+    run("SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0"})
+    run("SPUMONI_GPUS=0,0,0 (three workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0,0"})
+    for mb in (8, 16, 32, 128):
+        run(f"SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_SUPER_BATCH": str(mb << 20)})
+    run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
+    run("SPUMONI_REPORT_ONLY=1, again", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
+    run("SPUMONI_REPORT_ONLY=1 SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_GPUS": "0"})
+    for mb in (8, 16, 32):
+        run(f"SPUMONI_REPORT_ONLY=1 SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_SUPER_BATCH": str(mb << 20)})
+    run("-t 8 (a pool of eight)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 8"})
 # ---- MS mode: three output files side by side (lengths, pointers, report) ----
 if os.environ.get("E2E_MS", "1") != "0":
     dm = d + "/ms"; os.makedirs(dm, exist_ok=True)
@@ -134,6 +136,55 @@ if os.environ.get("E2E_MS", "1") != "0":
         print(f"   cmp {e} (files' tails as memory against plain writes): {'identical' if same else 'DIFFERENT'}", flush=True)
     import shutil
     shutil.rmtree(dm)
+
+# ---- run -m: the reads digested on the device before the walk (the declared C3 pipeline: a minimizer-digested index) ----
+if os.environ.get("E2E_DIGEST", "1") != "0":
+    from spumoni_amd import capi
+    dg = d + "/dig"; os.makedirs(dg, exist_ok=True)
+    k, w = 4, 11
+    print("   (digesting the genomes)", flush=True)
+    dig = capi.digester(0)
+    parts = []
+    for g in genomes:
+        for seq in (g, synth.revcomp(g)):
+            dd, _ = dig.digest_host(capi.SPX_DIGEST_PROMOTED, k, w, seq, np.array([0, seq.size], dtype=np.uint64))
+            parts.append(dd.copy())
+    dig.close()
+    print("   (indexing the digested text)", flush=True)
+    raw_d = synth.index_from_text(torch.from_numpy(np.concatenate(parts)).cuda(), with_samples=False).cpu()
+    open(f"{dg}/ref.bin", "w").write(">x\n")
+    raw_d.write_raw_files(f"{dg}/ref.bin")
+    write_null_db(f"{dg}/ref.bin.pmlnulldb", 3.0, [1, 2, 3, 3, 3, 3, 3])
+    os.symlink(f"{d}/reads.fa", f"{dg}/reads.fa")
+
+    def run_m(tag, extra_env):
+        env = dict(os.environ, **extra_env)
+        t0 = time.time()
+        print(f"   (starting: {tag})", flush=True)
+        r = subprocess.run(["timeout", "-s", "ABRT", os.environ.get("E2E_M_TIMEOUT", "120"), f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{dg}/ref", "-p", f"{dg}/reads.fa", "-P", "-c", "-m"], capture_output=True, env=env)
+        if r.returncode != 0:
+            print("   FAILED rc", r.returncode, r.stderr.decode(errors="replace")[-1500:], flush=True)
+            return
+        dt = time.time() - t0
+        err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
+        assert r.returncode == 0, err
+        import re
+        secs = [float(x) for x in re.findall(r"done\.\s+\(([0-9.]+) sec\)", err)]
+        load_s, proc_s = (secs + [0, 0])[:2]
+        print(f"== -P -c -m (k=4, w=11), {nreads} reads, {tag}: {dt:.2f}s wall; loading the index {load_s:.3f}s, processing the patterns {proc_s:.3f}s = "
+              f"{nreads / max(proc_s, 1e-9) / 1e6:.2f} M reads/s (pseudo_lengths {os.path.getsize(dg + '/reads.fa.pseudo_lengths') / 1e6:.0f} MB, "
+              f"report {os.path.getsize(dg + '/reads.fa.report') / 1e6:.0f} MB)")
+        for l in err.splitlines():
+            if "[timing]" in l:
+                print("   ", l.strip())
+        sys.stdout.flush()
+
+    run_m("SPUMONI_CACHE=write", {"SPUMONI_CACHE": "write"})
+    run_m("flat-layout cache", {})
+    run_m("flat-layout cache, again", {})
+    run_m("SPUMONI_MAP_OUTPUT=0", {"SPUMONI_MAP_OUTPUT": "0"})
+    import shutil
+    shutil.rmtree(dg)
 
 # ---- CPU: the oracle harness, file to file, one thread (the reference's -t 1 shape) ----
 run("GPU CLI on the CPU sample", f"{d}/sample.fa", {})
