@@ -27,6 +27,7 @@ def test_default_and_driver_command_lines_name_the_declared_c3():
     assert a.runs == mod.DECLARED_RUNS == 1_000_000_000 and a.sigma == 253 and a.reads == 10_000_000
     assert (a.read_len, a.bp_per_read, a.out_bits, a.scaling) == (44, 200, 16, "weak")
     assert a.want("dna_m200") and a.want("c4_ms_doc") and a.want("long_reads_c5") and a.want("real_bwt_digest_walk")
+    assert a.want("cli_file_to_file") and not a.want("real_bwt_large")  # (the large real BWT is opt-in: minutes of suffix sorting)
     assert 0 < a.cpu_seconds <= 5 and a.wall_budget > 240
     mod, a = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5"])  # the driver's line
     assert (a.gpus, a.steps, a.warmup, a.runs) == (8, 20, 5, 1_000_000_000)
@@ -34,6 +35,8 @@ def test_default_and_driver_command_lines_name_the_declared_c3():
     assert a.runs == 1 << 28 and not a.want("dna_m200") and a.scaling == "strong"
     mod, a = _bench(["--legs", "positive_100,c4_ms_doc"])
     assert a.want("c4_ms_doc") and a.want("positive_100") and not a.want("dna_m200")
+    mod, a = _bench(["--legs", "real_bwt_large"])
+    assert a.want("real_bwt_large") and not a.want("cli_file_to_file")
 
 
 def test_bytes_per_step_is_survey_8d():
