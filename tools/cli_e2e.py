@@ -97,6 +97,9 @@ if not quick:
     for mb in (8, 16, 32):
         run(f"SPUMONI_REPORT_ONLY=1 SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1", "SPUMONI_SUPER_BATCH": str(mb << 20)})
     run("-t 8 (a pool of eight)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 8"})
+    run("-t 4 (a pool of four)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 4"})
+    run("-t 4, report only", f"{d}/reads.fa", {"E2E_EXTRA": "-t 4", "SPUMONI_REPORT_ONLY": "1"})
+    run("-t 2, report only", f"{d}/reads.fa", {"E2E_EXTRA": "-t 2", "SPUMONI_REPORT_ONLY": "1"})
 # ---- MS mode: three output files side by side (lengths, pointers, report) ----
 if os.environ.get("E2E_MS", "1") != "0":
     dm = d + "/ms"; os.makedirs(dm, exist_ok=True)
