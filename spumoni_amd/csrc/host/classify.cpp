@@ -22,7 +22,6 @@
 #include <deque>
 #include <functional>
 #include <mutex>
-#include <shared_mutex>
 #include <thread>
 
 #include <fcntl.h>
@@ -957,7 +956,6 @@ struct Slot {
     uint64_t file_bytes[NFILES] = {};        // ... and its size there
     bool placed = false;
     uint64_t report_bytes = 0;               // bytes of its report lines (known from the ids)
-    uint64_t input_bytes = 0;                // bytes of the reads file it stands for (lines and their newlines)
     std::atomic<int> writers_left{0};
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
@@ -1158,8 +1156,8 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
 namespace {
 OutputFiles* g_live_outputs = nullptr;  // what a fatal exit has to settle (reads.cpp: leave -> the exit hook)
 std::mutex g_settle_mu;
-std::shared_mutex g_grow_mu;  // held (shared) while an extent is added to an output file ...
-bool g_growth_over = false;   // ... and (exclusively) to end that for good before the files are cut to their sizes
+std::mutex g_grow_mu;        // held while an extent is added to an output file ...
+bool g_growth_over = false;  // ... and to end that for good before the files are cut to their sizes
 // A fatal read ends the run while the other threads -- the device's copies, the pool -- may still be writing later
 // super-batches into the files' mapped tails: cutting the files to their logical ends turns those stores into SIGBUS.  The
 // process is on its way out; a thread that gets there simply stays there.
@@ -1168,7 +1166,7 @@ extern "C" void park_on_sigbus(int) {
 }
 void settle_outputs(bool run_is_over) {
     {
-        std::unique_lock<std::shared_mutex> gg(g_grow_mu);  // (an extent being added is finished first; none is begun after)
+        std::lock_guard<std::mutex> gg(g_grow_mu);  // (an extent being added is finished first; none is begun after)
         g_growth_over = true;
     }
     std::lock_guard<std::mutex> g(g_settle_mu);
@@ -1197,8 +1195,8 @@ bool outputs_can_be_mapped(const RunOptions& o) {
 
 // One more extent of `size` bytes (a multiple of 4096) at the file's prepared end: allocated (fallocate), mapped, its page
 // table entries made by a few threads, and -- the value streams -- page-locked for the device.  times[3]: what each step took.
-static bool add_extent(OutFile& of, uint64_t size, double times[3], bool pin) {
-    std::shared_lock<std::shared_mutex> grow_guard(g_grow_mu);
+static bool add_extent(OutFile& of, uint64_t size, double times[3]) {
+    std::lock_guard<std::mutex> grow_guard(g_grow_mu);
     if (g_growth_over) return false;
     const auto tick = [] { return std::chrono::steady_clock::now(); };
     const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
@@ -1232,7 +1230,7 @@ static bool add_extent(OutFile& of, uint64_t size, double times[3], bool pin) {
     e.off = off;
     e.size = size;
     e.base = (char*)m;
-    e.pinned = pin && of.pin_wanted && spx_host_register(m, size) == SPX_OK;
+    e.pinned = of.pin_wanted && spx_host_register(m, size) == SPX_OK;
     times[2] += since(t0);
     std::lock_guard<std::mutex> g(of.ext_mu);
     of.ext.push_back(e);
@@ -1250,7 +1248,7 @@ static void prepare_one(OutputFiles* out, int f, const std::string& final_path, 
     of.fd = fd;
     of.pin_wanted = pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin");
     double t[3] = {0, 0, 0};
-    if (!add_extent(of, (est + 4095) & ~4095ull, t, true)) {  // (a file system that cannot do it: the file is written the ordinary way)
+    if (!add_extent(of, (est + 4095) & ~4095ull, t)) {  // (a file system that cannot do it: the file is written the ordinary way)
         if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
         return;
     }
@@ -1258,15 +1256,12 @@ static void prepare_one(OutputFiles* out, int f, const std::string& final_path, 
     for (int i = 0; i < 3; ++i) out->prep_s[i] += t[i];
 }
 
-// While the run goes: the places handed out so far and the share of the reads file they stand for predict every file's final
-// size; where that lies beyond a file's prepared end, one more extent is added behind it (the predicted rest + 5 %;
-// SPUMONI_MAP_GROW: extents of that many bytes instead, for tests).  An estimate that was short then costs little: the
-// super-batches at the seam go through the writer thread, and the new extent is mapped but NOT page-locked -- registering
-// memory with the device while it works stalls it (a 256 MB extent registered mid-run took the e2e from 0.13 to 0.36 s) -- so
-// the text that lands there is copied in by the pool from the slot's buffer (the `nopin` rate, not the `pwrite` rate).
+// While the run goes: whenever a file's reserved end comes within `margin` of its prepared end, another extent is added behind
+// it (a quarter of what is there, between 256 MB and 2 GB; SPUMONI_MAP_GROW: bytes, for tests) -- an estimate that was short
+// then costs the super-batches that straddle a seam, which go through the writer thread, and nothing else.
 class OutputGrower {
 public:
-    OutputGrower(OutputFiles& out, uint64_t input_bytes) : out_(out), input_bytes_(std::max<uint64_t>(input_bytes, 1)) {
+    explicit OutputGrower(OutputFiles& out) : out_(out) {
         if (const char* e = std::getenv("SPUMONI_MAP_GROW")) fixed_ = (std::strtoull(e, nullptr, 10) + 4095) & ~4095ull;
         th_ = std::thread([this] { loop(); });
     }
@@ -1278,11 +1273,9 @@ public:
         cv_.notify_all();
         th_.join();
     }
-    // a super-batch that stands for `input` bytes of the reads file took its place
-    void poke(uint64_t input) {
+    void poke() {  // (a super-batch took its place: look again)
         {
             std::lock_guard<std::mutex> g(mu_);
-            consumed_ += input;
             ++pokes_;
         }
         cv_.notify_all();
@@ -1298,21 +1291,18 @@ private:
             cv_.wait(g, [&] { return stop_ || pokes_ != seen; });
             if (stop_) break;
             seen = pokes_;
-            const double share = std::min(1.0, (double)consumed_ / (double)input_bytes_);
             g.unlock();
             for (OutFile& of : out_.f) {
                 if (of.fd < 0 || !of.mapped() || failed_) continue;
-                const uint64_t have = of.prepared_end, used = of.reserved_now.load();
-                uint64_t step = 0;
-                if (fixed_) {
-                    if (used + fixed_ > have) step = fixed_;
-                } else if (share >= 0.02) {  // (a first super-batch or two say little)
-                    const double predicted = (double)used / share * 1.02;
-                    if (predicted > (double)have) step = ((uint64_t)((predicted - (double)have) * 1.05) + (1u << 20) + 4095) & ~4095ull;
-                }
-                if (step == 0) continue;
+                const uint64_t have = of.prepared_end;
+                // a quarter of what is there, at least 256 MB (for a small file: as much again) and at most 2 GB; begun when the
+                // places handed out come within two such steps of the prepared end
+                const uint64_t floor_ = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(64u << 10, have));
+                const uint64_t step = fixed_ ? fixed_ : std::min<uint64_t>(2ull << 30, std::max<uint64_t>(floor_, (have / 4 + 4095) & ~4095ull));
+                const uint64_t margin = 2 * step;
+                if (of.reserved_now.load() + margin <= have) continue;
                 double t[3] = {0, 0, 0};
-                if (add_extent(of, step, t, false))
+                if (add_extent(of, step, t))
                     grown_ += step;
                 else
                     failed_ = true;  // (out of space: what is left goes through the writer threads)
@@ -1321,12 +1311,11 @@ private:
         }
     }
     OutputFiles& out_;
-    const uint64_t input_bytes_;
     std::thread th_;
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false, failed_ = false;
-    uint64_t fixed_ = 0, pokes_ = 0, consumed_ = 0;
+    uint64_t fixed_ = 0, pokes_ = 0;
     std::atomic<uint64_t> grown_{0};
 };
 
@@ -1438,7 +1427,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     // before it is copied out -- their places are reserved; or it is formatted on the host and appended in input order.  The
     // report's lines have a size known from the ids: its places are reserved in every regime.
     for (int i = 0; i < NFILES; ++i) out.f[i].reserved_now.store(out.f[i].reserved);
-    std::unique_ptr<OutputGrower> grower_owner(new OutputGrower(out, input.file_bytes()));
+    std::unique_ptr<OutputGrower> grower_owner(new OutputGrower(out));
     OutputGrower& grower = *grower_owner;
     static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
     const bool no_len_text = o.report_only && !o.ms && o.write_report;
@@ -1469,7 +1458,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                     s.file_bytes[f] = want[f];
                 }
                 order.reserve(s.seq, out, want, s.file_off);
-                grower.poke(s.input_bytes);
+                grower.poke();
                 s.placed = true;
                 for (int f = 0; f < 3; ++f)
                     if (want[f]) dest[f] = out.f[f].at(s.file_off[f], want[f], true);
@@ -1593,8 +1582,6 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                 }
                 slots[(size_t)i].seq = next_seq++;
                 slots[(size_t)i].last = input_done;
-                slots[(size_t)i].input_bytes = 0;
-                for (const ReadFile::Range& r : ranges) slots[(size_t)i].input_bytes += r.bytes + (r.last - r.first);
                 seg_s += since(t0);
             }
             Slot& s = slots[(size_t)i];
