@@ -512,32 +512,10 @@ struct OutFile {
     int fd = -1;
     uint64_t end = 0;          // logical size: everything below is final (batches complete in input order)
     uint64_t reserved = 0;     // device-text runs: where the next super-batch's share starts (OffsetOrder)
-    // The file's tail as memory: extents [off, off + size) of the file, each mapped (MAP_SHARED) and -- the value streams --
-    // page-locked for the device.  The first is prepared while the index loads, from an estimate of the file's size; a helper
-    // thread (OutputGrower) adds more at the file's prepared end while the run goes, so that an estimate that was short costs a
-    // super-batch or two at the seam, not the rest of the file.  Append-only, under ext_mu.
-    struct Extent {
-        uint64_t off = 0, size = 0;
-        char* base = nullptr;
-        bool pinned = false;
-    };
-    std::deque<Extent> ext;
-    mutable std::mutex ext_mu;
-    uint64_t prepared_end = 0;  // extents cover [0, prepared_end)
-    std::atomic<uint64_t> reserved_now{0};  // `reserved`, for the grower to look at
-    bool pin_wanted = false;    // extents of this file are registered with the device
+    char* map = nullptr;       // the file's first map_size bytes as memory (MAP_SHARED), or null
+    uint64_t map_size = 0;
+    bool pinned = false;       // ... and page-locked: the device writes it
     std::string temp_path;     // prepared ahead of time under this name, renamed when the run starts
-    bool mapped() const {
-        std::lock_guard<std::mutex> g(ext_mu);
-        return !ext.empty();
-    }
-    // [off, off + bytes) as memory when one extent holds all of it (and is page-locked, if that is asked for); null otherwise
-    char* at(uint64_t off, uint64_t bytes, bool need_pinned) const {
-        std::lock_guard<std::mutex> g(ext_mu);
-        for (const Extent& e : ext)
-            if (off >= e.off && off + bytes <= e.off + e.size) return (need_pinned && !e.pinned) ? nullptr : e.base + (off - e.off);
-        return nullptr;
-    }
     void open(const std::string& path) {
         // A large output of an earlier run under the same name: truncating it gives its pages back synchronously
         // (0.2 s for 2 GB on tmpfs, inside "processing the patterns").  It is moved aside and removed on a thread
@@ -583,24 +561,20 @@ struct OutFile {
     }
     void append(const std::string& s) { append(s.data(), s.size()); }
     void drop_mapping() {
-        std::lock_guard<std::mutex> g(ext_mu);
-        for (Extent& e : ext) {
-            if (e.pinned) (void)spx_host_unregister(e.base);
-            ::munmap(e.base, e.size);
-        }
-        ext.clear();
-        prepared_end = 0;
+        if (!map) return;
+        if (pinned) (void)spx_host_unregister(map);
+        ::munmap(map, map_size);
+        map = nullptr;
+        map_size = 0;
+        pinned = false;
     }
     // the file ends where its last complete super-batch does (the prepared tail was an estimate; after a fatal read the
     // device may already have written later super-batches behind it)
     void settle(bool run_is_over) {
-        if (fd < 0 || !mapped()) return;
-        if (run_is_over) {  // (on a fatal exit other threads may still be looking: nothing is touched but the file)
-            std::lock_guard<std::mutex> g(ext_mu);
-            for (Extent& e : ext) {
-                if (e.pinned) (void)spx_host_unregister(e.base);
-                e.pinned = false;
-            }
+        if (fd < 0 || !map) return;
+        if (run_is_over && pinned) {  // (on a fatal exit other threads may still be looking: nothing is touched but the file)
+            (void)spx_host_unregister(map);
+            pinned = false;
         }
         if (::ftruncate(fd, (off_t)end) != 0) std::fprintf(stderr, "[spumoni-gpu] could not cut the output file to its size\n");
         // (the mapping itself is left to the end of the process: unmapping 2 GB is 75 ms that no one waits for there)
@@ -630,7 +604,6 @@ public:
         for (int f = 0; f < NFILES; ++f) {
             off[f] = out.f[f].reserved;
             out.f[f].reserved += bytes[f];
-            out.f[f].reserved_now.store(out.f[f].reserved);
         }
         next_++;
         cv_.notify_all();
@@ -876,7 +849,7 @@ void finish_batch(Pool& pool, const RunOptions& o, Outputs& out, const SuperBatc
     // the report's lines go straight to their place when that is memory
     char* report_base = nullptr;
     std::vector<uint64_t> rep_off;
-    if (o.write_report && out.f[F_REPORT].mapped()) {
+    if (o.write_report && out.f[F_REPORT].map) {
         rep_off.assign(nt + 1, 0);
         pool.run(nt, [&](size_t t) {
             uint64_t b = 0;
@@ -884,7 +857,7 @@ void finish_batch(Pool& pool, const RunOptions& o, Outputs& out, const SuperBatc
             rep_off[t + 1] = b;
         });
         for (size_t t = 0; t < nt; ++t) rep_off[t + 1] += rep_off[t];
-        report_base = out.f[F_REPORT].at(file_off[F_REPORT], rep_off[nt], false);
+        if (file_off[F_REPORT] + rep_off[nt] <= out.f[F_REPORT].map_size) report_base = out.f[F_REPORT].map + file_off[F_REPORT];
     }
     if (res.device_text) {
         RunOptions ro = o;  // only the report is left to format
@@ -896,8 +869,9 @@ void finish_batch(Pool& pool, const RunOptions& o, Outputs& out, const SuperBatc
         for (int i = 0; i < 3; ++i) {
             open_[i] = (res.streams & (1u << i)) && out.f[i].is_open();
             const uint64_t bytes = open_[i] ? res.line_start[i][nreads] : 0;
-            dest[i] = open_[i] ? out.f[i].at(file_off[i], bytes, false) : nullptr;
-            direct[i] = dest[i] && res.text_at[i] == dest[i];  // the device wrote it there
+            const bool fits = open_[i] && out.f[i].map && file_off[i] + bytes <= out.f[i].map_size;
+            dest[i] = fits ? out.f[i].map + file_off[i] : nullptr;
+            direct[i] = fits && res.text_at[i] == dest[i];  // the device wrote it there
         }
         pool.run(nt, [&](size_t t) {
             const size_t lo = nreads * t / nt, hi = nreads * (t + 1) / nt;
@@ -1156,8 +1130,6 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
 namespace {
 OutputFiles* g_live_outputs = nullptr;  // what a fatal exit has to settle (reads.cpp: leave -> the exit hook)
 std::mutex g_settle_mu;
-std::mutex g_grow_mu;        // held while an extent is added to an output file ...
-bool g_growth_over = false;  // ... and to end that for good before the files are cut to their sizes
 // A fatal read ends the run while the other threads -- the device's copies, the pool -- may still be writing later
 // super-batches into the files' mapped tails: cutting the files to their logical ends turns those stores into SIGBUS.  The
 // process is on its way out; a thread that gets there simply stays there.
@@ -1165,10 +1137,6 @@ extern "C" void park_on_sigbus(int) {
     for (;;) ::pause();
 }
 void settle_outputs(bool run_is_over) {
-    {
-        std::lock_guard<std::mutex> gg(g_grow_mu);  // (an extent being added is finished first; none is begun after)
-        g_growth_over = true;
-    }
     std::lock_guard<std::mutex> g(g_settle_mu);
     if (!g_live_outputs) return;
     {
@@ -1193,23 +1161,30 @@ bool outputs_can_be_mapped(const RunOptions& o) {
     return !(o.is_general_text || std::getenv("SPUMONI_HOST_FORMAT") || env_is("SPUMONI_MAP_OUTPUT", "0"));
 }
 
-// One more extent of `size` bytes (a multiple of 4096) at the file's prepared end: allocated (fallocate), mapped, its page
-// table entries made by a few threads, and -- the value streams -- page-locked for the device.  times[3]: what each step took.
-static bool add_extent(OutFile& of, uint64_t size, double times[3]) {
-    std::lock_guard<std::mutex> grow_guard(g_grow_mu);
-    if (g_growth_over) return false;
+// One file's tail as memory: created under a temporary name, `size` bytes allocated (fallocate), mapped, its page table
+// entries made by a few threads, and -- the value streams -- page-locked for the device.
+static void prepare_one(OutputFiles* out, int f, const std::string& final_path, uint64_t est, bool pin) {
     const auto tick = [] { return std::chrono::steady_clock::now(); };
     const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
-    const uint64_t off = of.prepared_end;  // (only one thread at a time extends a file: the preparer, then the grower)
+    OutFile& of = out->f[f];
+    of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
+    const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return;
+    register_leftover(of.temp_path);
+    const uint64_t size = (est + 4095) & ~4095ull;
     void* m = MAP_FAILED;
     auto t0 = tick();
-    if (::fallocate(of.fd, 0, (off_t)off, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, of.fd, (off_t)off);
-    if (m == MAP_FAILED) return false;
-    times[0] += since(t0);
+    if (::fallocate(fd, 0, 0, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) {  // (a file system that cannot do either: the file is written the ordinary way)
+        if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
+        of.fd = fd;
+        return;
+    }
+    const double s0 = since(t0);
     t0 = tick();
     {
         // the page table entries now, by a few threads, so that nothing faults inside the run
-        const unsigned nt = size >= (64u << 20) ? 4 : 1;
+        const unsigned nt = 4;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([=] {
@@ -1224,100 +1199,17 @@ static bool add_extent(OutFile& of, uint64_t size, double times[3]) {
             });
         for (auto& x : th) x.join();
     }
-    times[1] += since(t0);
+    const double s1 = since(t0);
     t0 = tick();
-    OutFile::Extent e;
-    e.off = off;
-    e.size = size;
-    e.base = (char*)m;
-    e.pinned = of.pin_wanted && spx_host_register(m, size) == SPX_OK;
-    times[2] += since(t0);
-    std::lock_guard<std::mutex> g(of.ext_mu);
-    of.ext.push_back(e);
-    of.prepared_end = off + size;
-    return true;
-}
-
-// One file's tail as memory: created under a temporary name, its first extent sized from the estimate.
-static void prepare_one(OutputFiles* out, int f, const std::string& final_path, uint64_t est, bool pin) {
-    OutFile& of = out->f[f];
-    of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
-    const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) return;
-    register_leftover(of.temp_path);
     of.fd = fd;
-    of.pin_wanted = pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin");
-    double t[3] = {0, 0, 0};
-    if (!add_extent(of, (est + 4095) & ~4095ull, t)) {  // (a file system that cannot do it: the file is written the ordinary way)
-        if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
-        return;
-    }
+    of.map = (char*)m;
+    of.map_size = size;
+    if (pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) of.pinned = spx_host_register(m, size) == SPX_OK;
     std::lock_guard<std::mutex> g(g_settle_mu);
-    for (int i = 0; i < 3; ++i) out->prep_s[i] += t[i];
+    out->prep_s[0] += s0;
+    out->prep_s[1] += s1;
+    out->prep_s[2] += since(t0);
 }
-
-// While the run goes: whenever a file's reserved end comes within `margin` of its prepared end, another extent is added behind
-// it (a quarter of what is there, between 256 MB and 2 GB; SPUMONI_MAP_GROW: bytes, for tests) -- an estimate that was short
-// then costs the super-batches that straddle a seam, which go through the writer thread, and nothing else.
-class OutputGrower {
-public:
-    explicit OutputGrower(OutputFiles& out) : out_(out) {
-        if (const char* e = std::getenv("SPUMONI_MAP_GROW")) fixed_ = (std::strtoull(e, nullptr, 10) + 4095) & ~4095ull;
-        th_ = std::thread([this] { loop(); });
-    }
-    ~OutputGrower() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        th_.join();
-    }
-    void poke() {  // (a super-batch took its place: look again)
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            ++pokes_;
-        }
-        cv_.notify_all();
-    }
-    uint64_t grown_bytes() const { return grown_.load(); }
-
-private:
-    void loop() {
-        std::unique_lock<std::mutex> g(mu_);
-        uint64_t seen = 0;
-        while (!stop_) {
-            // (a plain wait: gcc 11's ThreadSanitizer does not know pthread_cond_clockwait, which wait_for is made of)
-            cv_.wait(g, [&] { return stop_ || pokes_ != seen; });
-            if (stop_) break;
-            seen = pokes_;
-            g.unlock();
-            for (OutFile& of : out_.f) {
-                if (of.fd < 0 || !of.mapped() || failed_) continue;
-                const uint64_t have = of.prepared_end;
-                // a quarter of what is there, at least 256 MB (for a small file: as much again) and at most 2 GB; begun when the
-                // places handed out come within two such steps of the prepared end
-                const uint64_t floor_ = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(64u << 10, have));
-                const uint64_t step = fixed_ ? fixed_ : std::min<uint64_t>(2ull << 30, std::max<uint64_t>(floor_, (have / 4 + 4095) & ~4095ull));
-                const uint64_t margin = 2 * step;
-                if (of.reserved_now.load() + margin <= have) continue;
-                double t[3] = {0, 0, 0};
-                if (add_extent(of, step, t))
-                    grown_ += step;
-                else
-                    failed_ = true;  // (out of space: what is left goes through the writer threads)
-            }
-            g.lock();
-        }
-    }
-    OutputFiles& out_;
-    std::thread th_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    bool stop_ = false, failed_ = false;
-    uint64_t fixed_ = 0, pokes_ = 0;
-    std::atomic<uint64_t> grown_{0};
-};
 
 static uint64_t map_min_bytes() {
     // (SPUMONI_MAP_MIN / SPUMONI_MAP_FACTOR: tests map the tails of tiny files, and size them short so that a run crosses from
@@ -1426,9 +1318,6 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     // the run's regime (the same rule as run_on_device): the value files' text comes from the device, with its size known
     // before it is copied out -- their places are reserved; or it is formatted on the host and appended in input order.  The
     // report's lines have a size known from the ids: its places are reserved in every regime.
-    for (int i = 0; i < NFILES; ++i) out.f[i].reserved_now.store(out.f[i].reserved);
-    std::unique_ptr<OutputGrower> grower_owner(new OutputGrower(out));
-    OutputGrower& grower = *grower_owner;
     static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
     const bool no_len_text = o.report_only && !o.ms && o.write_report;
     const uint32_t run_streams = (no_len_text ? 0u : SPX_TEXT_LENGTHS) | (o.ms ? SPX_TEXT_POINTERS : 0u) | (o.use_doc ? SPX_TEXT_DOCS : 0u);
@@ -1458,10 +1347,9 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                     s.file_bytes[f] = want[f];
                 }
                 order.reserve(s.seq, out, want, s.file_off);
-                grower.poke();
                 s.placed = true;
                 for (int f = 0; f < 3; ++f)
-                    if (want[f]) dest[f] = out.f[f].at(s.file_off[f], want[f], true);
+                    if (want[f] && out.f[f].pinned && s.file_off[f] + want[f] <= out.f[f].map_size) dest[f] = out.f[f].map + s.file_off[f];
             };
             if (s.sb.nreads() > 0) run_on_device(set.ix[d], o, s.sb, max_value_thr, s.res, place);
             if (!s.placed) {
@@ -1602,8 +1490,6 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     for (auto& t : feeders) t.join();
     for (auto& w : workers) w.join();
     for (auto& w : writers) w.join();
-    const uint64_t grown = grower.grown_bytes();
-    grower_owner.reset();  // (joined before the files are cut)
     settle_outputs(true);  // the files end where their last super-batch does
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
@@ -1615,9 +1501,9 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     for (int f = 0; f < NFILES; ++f)
         if (out.f[f].is_open())
             std::fprintf(stderr, "[timing] writer %-15s %.3f s  (%.1f MB; %s)\n", fname[f], write_s[(size_t)f], (double)out.f[f].end / 1e6,
-                         out.f[f].mapped() ? "its tail was prepared as memory" : "plain writes");
-    std::fprintf(stderr, "[timing] output bytes: %.3f MB went straight into the files' pages, %.3f MB through the writer threads (files prepared in %.3f s beside the index load: allocate + map %.3f, page table entries %.3f, page-locking %.3f s; %.1f MB more prepared during the run)\n",
-                 (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s, out.prep_s[0], out.prep_s[1], out.prep_s[2], (double)grown / 1e6);
+                         out.f[f].map_size ? "its tail was prepared as memory" : "plain writes");
+    std::fprintf(stderr, "[timing] output bytes: %.3f MB went straight into the files' pages, %.3f MB through the writer threads (files prepared in %.3f s beside the index load: allocate + map %.3f, page table entries %.3f, page-locking %.3f s)\n",
+                 (double)direct_bytes.load() / 1e6, (double)staged_bytes.load() / 1e6, out.prepare_s, out.prep_s[0], out.prep_s[1], out.prep_s[2]);
     for (size_t d = 0; d < nworkers; ++d)
         std::fprintf(stderr, "[timing] gpu worker %zu          %.3f s  (%zu super-batches, copies included)  + headers / report %.3f s, waiting for input %.3f s\n", d,
                      dev_busy[d], dev_batches[d], dev_finish[d], dev_wait[d]);
