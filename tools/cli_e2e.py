@@ -24,7 +24,7 @@ raw.write_raw_files(f"{d}/ref.fa")
 write_null_db(f"{d}/ref.fa.pmlnulldb", 3.0, [1, 2, 3, 3, 3, 3, 3])
 nreads, m = int(os.environ.get("E2E_READS", "4000000")), 200
 ncpu = int(os.environ.get("E2E_CPU_READS", "50000"))
-seqs, offs = synth.sample_reads(text, nreads, m, seed=12)
+seqs, offs = synth.sample_reads(text, nreads, m, seed=12, null_fraction=float(os.environ.get("E2E_NULL_FRACTION", "0.5")))
 
 
 def write_fasta(path, lo, hi):
