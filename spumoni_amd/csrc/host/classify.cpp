@@ -1329,6 +1329,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     std::vector<double> dev_busy(nworkers, 0.0), dev_finish(nworkers, 0.0), dev_wait(nworkers, 0.0);
     std::vector<size_t> dev_batches(nworkers, 0);
     std::atomic<uint64_t> next_seq_to_run{0};
+    std::atomic<int64_t> first_on_device_us{-1}, last_off_device_us{0};
+    auto us_since_start = [&] { return (int64_t)(since(t_stage0) * 1e6); };
     auto device_worker = [&](size_t d) {
         for (;;) {
             const uint64_t seq = next_seq_to_run.fetch_add(1);
@@ -1338,6 +1340,10 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
             if (i < 0) break;
             parsed.drop(seq);
             const auto t0 = tick();
+            {
+                int64_t none = -1;
+                (void)first_on_device_us.compare_exchange_strong(none, us_since_start());
+            }
             Slot& s = slots[(size_t)i];
             // the super-batch's place in the files: reserved once, in input order, as soon as its sizes are known
             auto place = [&](const uint64_t bytes[3], char* dest[3]) {
@@ -1387,6 +1393,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
             }
             dev_finish[d] += since(t1);
             dev_batches[d]++;
+            last_off_device_us.store(us_since_start());
             s.writers_left.store(nfiles_open);
             done.put(s.seq, i);
         }
@@ -1490,7 +1497,13 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     for (auto& t : feeders) t.join();
     for (auto& w : workers) w.join();
     for (auto& w : writers) w.join();
+    // (the files' tails were prepared from an estimate on the generous side: what is too much is given back here, ~13 ms per
+    // 100 MB of allocated, mapped, page-locked pages -- profiles/r05_early_trim_experiment.txt on why not beside the run)
+    const double t_before_settle = since(t_stage0);
     settle_outputs(true);  // the files end where their last super-batch does
+    std::fprintf(stderr, "[timing] the first super-batch reached its device after %.3f s, the last left it after %.3f s, the files were complete after %.3f s "
+                         "and cut to their sizes after %.3f s\n",
+                 (double)first_on_device_us.load() / 1e6, (double)last_off_device_us.load() / 1e6, t_before_settle, since(t_stage0));
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
     double p0 = 0, p1 = 0;
