@@ -570,13 +570,25 @@ struct OutFile {
     }
     // the file ends where its last complete super-batch does (the prepared tail was an estimate; after a fatal read the
     // device may already have written later super-batches behind it)
+    double settle_s[3] = {0, 0, 0};  // giving the excess back: un-registering, (unused), the cut itself
     void settle(bool run_is_over) {
         if (fd < 0 || !map) return;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const auto t0 = now();
         if (run_is_over && pinned) {  // (on a fatal exit other threads may still be looking: nothing is touched but the file)
             (void)spx_host_unregister(map);
             pinned = false;
         }
+        const auto t1 = now();
+        // (cutting N mapped pages off a file is two jobs under the inode's lock, the page table entries and the pages; dropping
+        // the entries ahead with madvise(DONTNEED) on several threads made it slower on the GPU box, 45 -> 70-160 ms:
+        // profiles/r05_early_trim_experiment.txt)
+        const auto t2 = now();
         if (::ftruncate(fd, (off_t)end) != 0) std::fprintf(stderr, "[spumoni-gpu] could not cut the output file to its size\n");
+        settle_s[0] = secs(t0, t1);
+        settle_s[1] = secs(t1, t2);
+        settle_s[2] = secs(t2, now());
         // (the mapping itself is left to the end of the process: unmapping 2 GB is 75 ms that no one waits for there)
     }
     ~OutFile() {
@@ -1146,7 +1158,14 @@ void settle_outputs(bool run_is_over) {
         sigemptyset(&sa.sa_mask);
         (void)::sigaction(SIGBUS, &sa, nullptr);
     }
-    for (OutFile& f : g_live_outputs->f) f.settle(run_is_over);
+    if (run_is_over) {  // (the files side by side: every inode has its own lock)
+        std::vector<std::thread> th;
+        for (OutFile& f : g_live_outputs->f)
+            if (f.fd >= 0 && f.map) th.emplace_back([&f] { f.settle(true); });
+        for (auto& x : th) x.join();
+    } else {
+        for (OutFile& f : g_live_outputs->f) f.settle(false);
+    }
     g_live_outputs = nullptr;
 }
 void settle_outputs_at_exit() { settle_outputs(false); }
@@ -1502,8 +1521,10 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     const double t_before_settle = since(t_stage0);
     settle_outputs(true);  // the files end where their last super-batch does
     std::fprintf(stderr, "[timing] the first super-batch reached its device after %.3f s, the last left it after %.3f s, the files were complete after %.3f s "
-                         "and cut to their sizes after %.3f s\n",
-                 (double)first_on_device_us.load() / 1e6, (double)last_off_device_us.load() / 1e6, t_before_settle, since(t_stage0));
+                         "and cut to their sizes after %.3f s (un-registering %.3f, the cut %.3f s)\n",
+                 (double)first_on_device_us.load() / 1e6, (double)last_off_device_us.load() / 1e6, t_before_settle, since(t_stage0),
+                 out.f[0].settle_s[0] + out.f[1].settle_s[0] + out.f[2].settle_s[0] + out.f[3].settle_s[0],
+                 out.f[0].settle_s[2] + out.f[1].settle_s[2] + out.f[2].settle_s[2] + out.f[3].settle_s[2]);
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
     double p0 = 0, p1 = 0;
