@@ -137,7 +137,8 @@ int spx_index_copy_text(spx_index *ix, uint8_t *out, uint64_t capacity, int wher
  * none) -- the caller drops ">id\n" into the gap, ids never travel.  out_bytes[i] = size of stream i (0: not
  * asked for).  spx_query_text_fetch then copies the streams (and, when line_start[i] is given, the nreads + 1
  * record offsets) into the caller's buffers (page-locked ones copy at DMA speed) -- the next call on the
- * same index after a successful begin, from the same thread.                                             */
+ * same index after a successful begin, from the same thread.  out_class (when given) must stay valid until
+ * spx_query_text_fetch returns: the class records travel with the text.                                  */
 #define SPX_TEXT_LENGTHS 1u
 #define SPX_TEXT_POINTERS 2u
 #define SPX_TEXT_DOCS 4u
@@ -145,6 +146,13 @@ int spx_query_text_begin(spx_index *ix, int mode, int digest_kind, uint32_t k, u
                          const uint64_t *offsets, uint64_t nreads, const uint32_t *gap, uint32_t streams,
                          spx_class *out_class, uint64_t bin_width, uint64_t max_value_thr, uint64_t out_bytes[3]);
 int spx_query_text_fetch(spx_index *ix, char *text[3], uint64_t *line_start[3]);
+/* Optional, before a run of such calls: allocates the device scratch a begin / fetch pair of up to max_chars characters in
+ * max_reads reads will need (text_bytes[i]: the expected size of stream i, or NULL), so that the first batch does not pay for
+ * it (~10 ms) and no buffer has to grow -- free + allocate, a device-wide synchronisation -- while other query contexts of
+ * the same device are at work.  A hint, not a limit.  (The reference has no counterpart: its vectors are std::vectors per
+ * read, compute_ms_pml.cpp:238-245.)                                                                                      */
+int spx_query_text_reserve(spx_index *ix, int mode, int digest_kind, uint32_t k, uint64_t max_chars, uint64_t max_reads,
+                           uint32_t streams, int with_class, const uint64_t text_bytes[3]);
 
 /* ---- flat-layout cache and replication -------------------------------------
  * pml_t / ms_t deserialise their index on every run (compute_ms_pml.cpp:700-721,

@@ -58,6 +58,7 @@ EXPORTS = [
     "spx_index_source_tag",
     "spx_query_text_begin",
     "spx_query_text_fetch",
+    "spx_query_text_reserve",
 ]
 SPX_TEXT_LENGTHS, SPX_TEXT_POINTERS, SPX_TEXT_DOCS = 1, 2, 4
 SPX_TEXT_UNCHECKED = 2
@@ -124,6 +125,7 @@ def lib() -> C.CDLL:
         L.spx_index_source_tag.argtypes = [vp]
         L.spx_query_text_begin.argtypes = [vp, i32, i32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, C.c_uint32, vp, u64, u64, vp]
         L.spx_query_text_fetch.argtypes = [vp, vp, vp]
+        L.spx_query_text_reserve.argtypes = [vp, i32, i32, C.c_uint32, u64, u64, C.c_uint32, i32, vp]
         L.spx_query_batch.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
         L.spx_query_batch_device.argtypes = [vp, i32, vp, vp, u64, u64, vp, vp, vp, vp, u64, u64, vp]
         L.spx_query_batch16.argtypes = [vp, i32, vp, vp, u64, vp, vp, vp, vp, u64, u64]
@@ -346,6 +348,14 @@ class Index:
         _check(lib().spx_query_text_fetch(self._h, C.cast(tp, C.c_void_p), C.cast(lp, C.c_void_p)))
         return {"text": [None if b is None else b[: int(nbytes[i])].tobytes() for i, b in enumerate(bufs)],
                 "line_start": starts, "class": None if cls_ is None else cls_[:nreads]}
+
+    def reserve_text(self, mode, max_chars, max_reads, streams=SPX_TEXT_LENGTHS, classify=False, digest=(0, 0), text_bytes=None):
+        """spx_query_text_reserve: the device scratch of query_text calls up to this size, allocated now (a hint)."""
+        tb = None
+        if text_bytes is not None:
+            tb = (C.c_uint64 * 3)(*[int(x) for x in text_bytes])
+        _check(lib().spx_query_text_reserve(self._h, mode, digest[0], digest[1], int(max_chars), int(max_reads), streams,
+                                            1 if classify else 0, None if tb is None else C.cast(tb, C.c_void_p)))
 
     # -- queries, device buffers (torch tensors on self.device) -------------
     def query_device(self, mode, d_seqs, d_offs, total_chars, d_lengths=None, d_pointers=None, d_docs=None,

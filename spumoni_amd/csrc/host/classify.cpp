@@ -184,6 +184,50 @@ void IndexSet::load(const RunOptions& o) {
         if (!ix[i]) fatal_error("%s", spx_last_error());
         std::fprintf(stderr, "[timing] worker %zu: a second query context on device %d (shares the arrays of worker %zu)\n", i, devs[i], src);
     }
+    // every worker's device scratch for a full super-batch, now: the first super-batch of each worker otherwise allocates it
+    // inside the timed run (10 ms alone, 17-20 ms with two or three workers of one device queueing for the allocator), and a
+    // buffer that grows mid-run is freed first, which synchronises the whole device (profiles/r05_cli_overlap.txt)
+    struct stat rs;
+    if (!o.is_general_text && !std::getenv("SPUMONI_HOST_FORMAT") && ::stat(o.pattern_file.c_str(), &rs) == 0 && rs.st_size > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t fsize = (uint64_t)rs.st_size;
+        const uint64_t chars = std::min<uint64_t>(o.super_batch_chars, fsize) + 65536;
+        const uint64_t reads_guess = chars / 100 + 4096;
+        const bool report_only = o.report_only && !o.ms && o.write_report;
+        const bool digest = o.use_promotions || o.use_dna_letters;
+        const uint32_t streams = (report_only ? 0u : SPX_TEXT_LENGTHS) | (o.ms ? SPX_TEXT_POINTERS : 0u) | (o.use_doc ? SPX_TEXT_DOCS : 0u);
+        const uint64_t text_bytes[3] = {chars * 3 + reads_guess * 40, chars * 11 + reads_guess * 40, chars * 3 + reads_guess * 40};
+        if (streams != 0) {
+            for (size_t i = 0; i < nwork; ++i)
+                if (spx_query_text_reserve(ix[i], o.ms ? SPX_MODE_MS : SPX_MODE_PML, digest ? (o.use_promotions ? SPX_DIGEST_PROMOTED : SPX_DIGEST_DNA) : 0,
+                                           (uint32_t)o.k, chars, reads_guess, streams, o.write_report ? 1 : 0, digest ? nullptr : text_bytes) != SPX_OK)
+                    std::fprintf(stderr, "[spumoni-gpu] device scratch not reserved ahead of the run (%s): it will be allocated by the first super-batches\n", spx_last_error());
+            // ... and one tiny query per worker: the first launch of every kernel on the handle's stream, the scan's temporary
+            // storage, the published words -- 6 of the first super-batch's 7.6 ms (profiles/r05_cli_overlap.txt)
+            if (!digest) {
+                static const uint8_t warm_seq[64] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C',
+                                                     'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T',
+                                                     'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T'};
+                const uint64_t warm_off[3] = {0, 40, 64};
+                const uint32_t warm_gap[2] = {3, 3};
+                std::vector<std::thread> th;
+                for (size_t i = 0; i < nwork; ++i)
+                    th.emplace_back([&, i] {
+                        spx_class cls[2];
+                        uint64_t bytes[3] = {0, 0, 0};
+                        if (spx_query_text_begin(ix[i], o.ms ? SPX_MODE_MS : SPX_MODE_PML, 0, (uint32_t)o.k, (uint32_t)o.w, warm_seq, warm_off, 2, warm_gap, streams,
+                                                 o.write_report ? cls : nullptr, o.bin_size ? o.bin_size : 1, 1, bytes) != SPX_OK)
+                            return;  // (nothing depends on it)
+                        std::vector<char> t0(bytes[0] + 1), t1(bytes[1] + 1), t2(bytes[2] + 1);
+                        char* tp[3] = {t0.data(), t1.data(), t2.data()};
+                        (void)spx_query_text_fetch(ix[i], tp, nullptr);
+                    });
+                for (auto& t : th) t.join();
+            }
+            std::fprintf(stderr, "[timing] device scratch of %zu worker%s reserved in %.3f s\n", nwork, nwork > 1 ? "s" : "",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
 }
 
 size_t max_value_threshold(double percentile_value, bool is_pml, bool use_promotions, bool use_dna_letters) {
@@ -395,6 +439,30 @@ struct Results {
 // output file there, in input order, and may name, per stream, memory of the file itself for the text to land in
 // (dest[i] stays null: the slot's page-locked buffer is used and a writer thread copies it).
 using PlaceFn = std::function<void(const uint64_t bytes[3], char* dest[3])>;
+// SPUMONI_CALL_TRACE=1: when every worker entered and left the library (begin = copy in + walk + sizes, fetch = digits + copy
+// out), microseconds on one clock -- who waited for whom on the device (tools/r05_overlap.sh)
+struct CallTrace {
+    std::mutex mu;
+    struct Rec { const void* ix; const char* what; double t0, t1; };
+    std::vector<Rec> recs;
+    const bool on = std::getenv("SPUMONI_CALL_TRACE") != nullptr;
+    const std::chrono::steady_clock::time_point origin = std::chrono::steady_clock::now();
+    double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - origin).count() * 1e3; }
+    void add(const void* ix, const char* what, double t0) {
+        if (!on) return;
+        const double t1 = now();
+        std::lock_guard<std::mutex> g(mu);
+        recs.push_back(Rec{ix, what, t0, t1});
+    }
+    void print() {
+        if (!on || recs.empty()) return;
+        std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.t0 < b.t0; });
+        const double base = recs.front().t0;
+        for (const Rec& r : recs) std::fprintf(stderr, "[calls] %p %-6s %8.3f .. %8.3f  (%.3f ms)\n", r.ix, r.what, r.t0 - base, r.t1 - base, r.t1 - r.t0);
+        recs.clear();
+    }
+};
+CallTrace g_calls;
 void run_on_device(spx_index* ix, const RunOptions& o, SuperBatch& sb, size_t max_value_thr, Results& res, const PlaceFn& place) {
     const size_t nreads = sb.nreads();
     const uint64_t total = sb.offs.back();
@@ -416,10 +484,12 @@ void run_on_device(spx_index* ix, const RunOptions& o, SuperBatch& sb, size_t ma
         // the output files' text is written on the device (compute_ms_pml.cpp:1001-1010, 1182-1205): what comes back
         // over PCIe is the files' new tail, with room for every ">id\n"
         uint64_t bytes[3] = {0, 0, 0};
+        const double tc0 = g_calls.now();
         rc = spx_query_text_begin(ix, o.ms ? SPX_MODE_MS : SPX_MODE_PML, digest ? kind : 0, (uint32_t)o.k, (uint32_t)o.w,
                                   sb.seqs.data(), sb.offs.data(), nreads, sb.gap.data(), streams,
                                   o.write_report ? res.cls.data() : nullptr, o.bin_size, max_value_thr, bytes);
         if (rc != SPX_OK) fatal_error("%s", spx_last_error());
+        g_calls.add(ix, "begin", tc0);
         char* tp[3] = {nullptr, nullptr, nullptr};
         uint64_t* lp[3] = {nullptr, nullptr, nullptr};
         place(bytes, tp);
@@ -436,7 +506,9 @@ void run_on_device(spx_index* ix, const RunOptions& o, SuperBatch& sb, size_t ma
             res.line_start[i].resize_uninit(nreads + 1);
             lp[i] = res.line_start[i].data();
         }
+        const double tc1 = g_calls.now();
         rc = spx_query_text_fetch(ix, tp, lp);
+        g_calls.add(ix, "fetch", tc1);
         if (rc != SPX_OK) fatal_error("%s", spx_last_error());
         if (digest) {  // (only a digested read can come back without values: the worker looks for the first one)
             res.beg.resize(nreads);
@@ -1526,6 +1598,7 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                  out.f[0].settle_s[0] + out.f[1].settle_s[0] + out.f[2].settle_s[0] + out.f[3].settle_s[0],
                  out.f[0].settle_s[2] + out.f[1].settle_s[2] + out.f[2].settle_s[2] + out.f[3].settle_s[2]);
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
+    g_calls.print();
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)
     double p0 = 0, p1 = 0;
     for (int fi = 0; fi < NFEED; ++fi) p0 += parse_s[(size_t)fi][0], p1 += parse_s[(size_t)fi][1];

@@ -125,6 +125,7 @@ void spx_index_free(spx_index* ix) {
     SPX_FT("arrays released");
     if (ix->counters) (void)hipFree(ix->counters);
     if (ix->ctx_stream) (void)hipStreamDestroy(ix->ctx_stream);
+    if (ix->h_pub) (void)hipHostFree(ix->h_pub);
     SPX_FT("stream destroyed");
     for (auto& st : ix->pipe_s)
         if (st) (void)hipStreamDestroy(st);
@@ -163,6 +164,29 @@ static void default_charhash(uint8_t out[4]) {
 static int ctx_stream_of(spx_index* ix, hipStream_t* out) {
     if (!ix->ctx_stream) SPX_HIP(hipStreamCreateWithFlags(&ix->ctx_stream, hipStreamNonBlocking));
     *out = ix->ctx_stream;
+    return SPX_OK;
+}
+
+// Words the host is waiting for, written into page-locked host memory by a kernel (spx_internal.h: h_pub): dst[i] = *src[i]
+// (0 for a null source) for i < 4, then nwords words of `more`.
+struct PubSrc {
+    const uint64_t* one[4];
+    const uint64_t* more;
+    int nmore;
+};
+__global__ void k_publish(uint64_t* dst, PubSrc src) {
+    const int t = (int)threadIdx.x;
+    if (t < 4) dst[t] = src.one[t] ? *src.one[t] : 0;
+    if (t >= 4 && t - 4 < src.nmore) dst[t] = src.more[t - 4];
+    __threadfence_system();
+}
+static int publish(spx_index* ix, const PubSrc& src, hipStream_t st) {
+    if (!ix->h_pub) {
+        SPX_HIP(hipHostMalloc((void**)&ix->h_pub, 64 * sizeof(uint64_t), hipHostMallocMapped));
+        SPX_HIP(hipHostGetDevicePointer((void**)&ix->h_pub_dev, ix->h_pub, 0));
+    }
+    k_publish<<<1, 64, 0, st>>>(ix->h_pub_dev, src);
+    SPX_HIP(hipGetLastError());
     return SPX_OK;
 }
 
@@ -1186,6 +1210,17 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         fprintf(stderr, "[spx] text_begin: %-28s %.2f ms\n", what, (t - t_mark) * 1e3);
         t_mark = t;
     };
+    // SPX_PHASE_TRACE=1: the device's own times of a call's phases (events on the handle's stream, read after the call's one
+    // synchronisation: nothing is added to the stream's work) -- how long the copy in / the kernels / the copy out of one
+    // query context take while another context of the same device is at work (tools/r05_overlap.sh)
+    static const bool phase_trace = getenv("SPX_PHASE_TRACE") != nullptr;
+    static thread_local hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto mark = [&](int i) {
+        if (!phase_trace) return;
+        if (!pe[i]) (void)hipEventCreate(&pe[i]);
+        (void)hipEventRecord(pe[i], st);
+    };
+    mark(0);
     const uint64_t total_in = nreads ? offsets[nreads] : 0;
     void *dseq = nullptr, *doff = nullptr, *dgap = nullptr;
     const uint64_t padded = ((total_in + 3) / 4) * 4 + 32;
@@ -1196,6 +1231,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     SPX_HIP(hipMemsetAsync((char*)dseq + total_in, 0, padded - total_in, st));
     SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     if (gap) SPX_HIP(hipMemcpyAsync(dgap, gap, nreads * 4, hipMemcpyHostToDevice, st));
+    mark(1);
     lap("copy in");
     const uint8_t* wseq = (const uint8_t*)dseq;
     const uint64_t* woff = (const uint64_t*)doff;
@@ -1213,8 +1249,12 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         rc = digest_for_walk(ix, mode, want_len || out_class != nullptr, digest_kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff,
                              nreads, total_in, (uint8_t*)dd, cap, (uint64_t*)ddo, st, &in_starts);
         if (rc != SPX_OK) return rc;
-        SPX_HIP(hipMemcpyAsync(&total, (uint64_t*)ddo + nreads, 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipStreamSynchronize(st));
+        {
+            PubSrc ps{{(const uint64_t*)ddo + nreads, nullptr, nullptr, nullptr}, nullptr, 0};
+            if ((rc = publish(ix, ps, st)) != SPX_OK) return rc;
+            SPX_HIP(hipStreamSynchronize(st));
+            total = ix->h_pub[0];
+        }
         wseq = (const uint8_t*)dd;
         woff = (const uint64_t*)ddo;
     }
@@ -1227,6 +1267,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     rc = query_device_impl(ix, mode, wseq, woff, nreads, total, (uint32_t*)dlen, (uint64_t*)dptr, (uint32_t*)ddoc,
                            (spx_class*)dcls, bin_width, max_value_thr, st, narrow, in_starts);
     if (rc != SPX_OK) return rc;
+    mark(2);
     lap("[digest +] walk");
     // count + scan per stream, then ONE read-back of the three sizes
     const size_t cub = text_scan_bytes(nreads);
@@ -1245,13 +1286,26 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
                                     (uint64_t*)ls[i], dcub, cub, st)) != SPX_OK)
             return rc;
     }
-    for (int i = 0; i < 3; ++i)
-        if (vals[i]) SPX_HIP(hipMemcpyAsync(&out_bytes[i], (uint64_t*)ls[i] + nreads, 8, hipMemcpyDeviceToHost, st));
-    // the class records and the counters are ready since the walk: they travel under the digits' kernels
+    // the three sizes and the walk's counters: published, not copied (h_pub); the class records travel with the text
     WalkCounters wc;
-    if (out_class) SPX_HIP(hipMemcpyAsync(out_class, dcls, nreads * sizeof(spx_class), hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipMemcpyAsync(&wc, ix->counters, sizeof wc, hipMemcpyDeviceToHost, st));
-    SPX_HIP(hipStreamSynchronize(st));
+    {
+        PubSrc ps{{nullptr, nullptr, nullptr, nullptr}, (const uint64_t*)ix->counters, (int)(sizeof wc / 8)};
+        for (int i = 0; i < 3; ++i)
+            if (vals[i]) ps.one[i] = (const uint64_t*)ls[i] + nreads;
+        if ((rc = publish(ix, ps, st)) != SPX_OK) return rc;
+        mark(3);
+        SPX_HIP(hipStreamSynchronize(st));
+        if (phase_trace) {
+            float a = 0, b = 0, c = 0;
+            (void)hipEventElapsedTime(&a, pe[0], pe[1]);
+            (void)hipEventElapsedTime(&b, pe[1], pe[2]);
+            (void)hipEventElapsedTime(&c, pe[2], pe[3]);
+            fprintf(stderr, "[phases] %p begin: copy in %.3f  walk %.3f  sizes %.3f ms\n", (void*)ix, a, b, c);
+        }
+        for (int i = 0; i < 3; ++i) out_bytes[i] = vals[i] ? ix->h_pub[i] : 0;
+        std::memcpy(&wc, ix->h_pub + 4, sizeof wc);
+    }
+    ix->text_cls_host = out_class;
     lap("count + scan");
     for (int i = 0; i < 3; ++i) {
         if (!vals[i]) continue;
@@ -1291,6 +1345,12 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
         if (rc != SPX_OK) return rc;
     }
     static const bool timing = getenv("SPX_TIMING") != nullptr;
+    static const bool phase_trace = getenv("SPX_PHASE_TRACE") != nullptr;
+    static thread_local hipEvent_t fe[2] = {nullptr, nullptr};
+    if (phase_trace) {
+        if (!fe[0]) (void)hipEventCreate(&fe[0]), (void)hipEventCreate(&fe[1]);
+        (void)hipEventRecord(fe[0], st);
+    }
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     for (int i = 0; i < 3; ++i) {
         if (ix->text_bytes[i] == 0) continue;
@@ -1298,12 +1358,74 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
         if (line_start && line_start[i])
             SPX_HIP(hipMemcpyAsync(line_start[i], ix->scratch[13 + i].p, (ix->text_nreads + 1) * 8, hipMemcpyDeviceToHost, st));
     }
+    if (ix->text_cls_host)
+        SPX_HIP(hipMemcpyAsync(ix->text_cls_host, ix->scratch[5].p, ix->text_nreads * sizeof(spx_class), hipMemcpyDeviceToHost, st));
+    if (phase_trace) (void)hipEventRecord(fe[1], st);
     SPX_HIP(hipStreamSynchronize(st));
+    if (phase_trace) {
+        float a = 0;
+        (void)hipEventElapsedTime(&a, fe[0], fe[1]);
+        fprintf(stderr, "[phases] %p fetch: copy out %.3f ms (behind the digits' kernels)\n", (void*)ix, a);
+    }
+    ix->text_cls_host = nullptr;
     ix->text_ready = false;
     if (timing)
         fprintf(stderr, "[spx] text_fetch: %.2f ms for %.1f MB\n",
                 (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3,
                 (ix->text_bytes[0] + ix->text_bytes[1] + ix->text_bytes[2]) / 1e6);
+    return SPX_OK;
+}
+
+// The scratch a spx_query_text_begin / _fetch pair of up to max_chars characters in max_reads reads will ask for, allocated now:
+// the first super-batch of a run otherwise pays for it (~300 MB of hipMalloc at ~30 ms / GB: 10 ms of a 1.5 ms call, and the
+// workers of one device queue behind each other for it), and a scratch buffer that has to GROW mid-run is freed first -- a
+// device-wide synchronisation under every other worker's feet.  A hint: whatever turns out larger still grows on demand.
+int spx_query_text_reserve(spx_index* ix, int mode, int digest_kind, uint32_t k, uint64_t max_chars, uint64_t max_reads,
+                           uint32_t streams, int with_class, const uint64_t text_bytes[3]) {
+    if (!ix || (mode != SPX_MODE_PML && mode != SPX_MODE_MS)) {
+        set_error("spx_query_text_reserve: index and a mode");
+        return SPX_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(ix->mu);
+    std::lock_guard<std::mutex> hg(ix->host_mu);
+    SPX_HIP(hipSetDevice(ix->device));
+    hipStream_t st = nullptr;
+    int rc;
+    if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    const bool want_len = streams & SPX_TEXT_LENGTHS, want_ptr = streams & SPX_TEXT_POINTERS, want_doc = streams & SPX_TEXT_DOCS;
+    void* p = nullptr;
+    const uint64_t padded = ((max_chars + 3) / 4) * 4 + 32;
+    if ((rc = ensure_scratch(ix, digest_kind ? 6 : 0, padded, &p)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 1, (max_reads + 1) * 8, &p)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 8, (max_reads + 1) * 4, &p)) != SPX_OK) return rc;
+    uint64_t total = max_chars;
+    if (digest_kind) {
+        if ((rc = ensure_scratch(ix, 0, spx_digest_capacity(digest_kind, k, max_chars), &p)) != SPX_OK) return rc;
+        if ((rc = ensure_scratch(ix, 7, (max_reads + 1) * 8, &p)) != SPX_OK) return rc;
+        // (the vectors are sized from the digested total, known only per batch: what an undigested batch would need is the bound)
+    }
+    const bool need_len = want_len || (mode == SPX_MODE_MS && with_class);
+    if (need_len && (rc = ensure_scratch(ix, 2, (total + 8) * 4, &p)) != SPX_OK) return rc;
+    if (mode == SPX_MODE_MS && (rc = ensure_scratch(ix, 3, (total + 1) * 8, &p)) != SPX_OK) return rc;
+    if (want_doc && (rc = ensure_scratch(ix, 4, (total + 8) * 4, &p)) != SPX_OK) return rc;
+    if (with_class && (rc = ensure_scratch(ix, 5, (max_reads + 1) * sizeof(spx_class), &p)) != SPX_OK) return rc;
+    if ((rc = ensure_scratch(ix, 9, text_scan_bytes(max_reads) + 256, &p)) != SPX_OK) return rc;
+    const bool on[3] = {want_len, want_ptr && mode == SPX_MODE_MS, want_doc};
+    for (int i = 0; i < 3; ++i) {
+        if (!on[i]) continue;
+        if ((rc = ensure_scratch(ix, 10 + i, (max_reads + 2) * 8, &p)) != SPX_OK) return rc;
+        if ((rc = ensure_scratch(ix, 13 + i, (max_reads + 2) * 8, &p)) != SPX_OK) return rc;
+        if (text_bytes && text_bytes[i] && (rc = ensure_scratch(ix, 16 + i, text_bytes[i] + 64, &p)) != SPX_OK) return rc;
+    }
+    if (mode == SPX_MODE_PML && need_len) {  // the walk's reset bits (prepare_len_mask)
+        const uint64_t pairs = (total >> 7) + max_reads + 2;
+        if ((rc = chunk_scratch(ix, 8, pairs * 16, &p)) != SPX_OK) return rc;
+    }
+    if (!ix->h_pub) {
+        PubSrc none{{nullptr, nullptr, nullptr, nullptr}, nullptr, 0};
+        if ((rc = publish(ix, none, st)) != SPX_OK) return rc;
+    }
+    SPX_HIP(hipStreamSynchronize(st));
     return SPX_OK;
 }
 

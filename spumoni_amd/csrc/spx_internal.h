@@ -200,6 +200,13 @@ struct spx_index {
     uint64_t text_bytes[3] = {0, 0, 0};
     uint64_t text_nreads = 0;
     bool text_ready = false;
+    spx_class* text_cls_host = nullptr;  // the class records travel with the text (spx_query_text_fetch)
+    // A few words the host waits for at the end of a step (stream sizes, the digested total, the walk's counters): written by
+    // a kernel into page-locked host memory, NOT copied -- a device-to-host copy of 8 bytes queues on the copy engine behind
+    // whatever another query context of the same device is copying out (1.4 ms per super-batch of text), which made
+    // spx_query_text_begin of one worker wait for spx_query_text_fetch of the other (profiles/r05_cli_overlap.txt).
+    uint64_t* h_pub = nullptr;      // host address
+    uint64_t* h_pub_dev = nullptr;  // the same memory as the device sees it
     int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
     int chunk_shift = 0;  // "chunk_shift" option: log2 of the chunk size (0 = automatic)
     int chunk_len = 0;    // "chunk_len" option: chunk size in characters (rounded up to 16; 0 = automatic)

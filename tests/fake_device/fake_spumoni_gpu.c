@@ -559,6 +559,16 @@ int spx_query_text_begin(spx_index *ix, int mode, int digest_kind, uint32_t k, u
     return rc;
 }
 
+int spx_query_text_reserve(spx_index *ix, int mode, int digest_kind, uint32_t k, uint64_t max_chars, uint64_t max_reads,
+                           uint32_t streams, int with_class, const uint64_t text_bytes[3]) {
+    (void)digest_kind; (void)k; (void)max_chars; (void)max_reads; (void)streams; (void)with_class; (void)text_bytes;
+    if (!ix || (mode != SPX_MODE_PML && mode != SPX_MODE_MS)) {
+        set_error("spx_query_text_reserve: index and a mode");
+        return SPX_E_ARG;
+    }
+    return SPX_OK; /* (nothing to allocate ahead on the host) */
+}
+
 int spx_query_text_fetch(spx_index *ix, char *text[3], uint64_t *line_start[3]) {
     if (!ix || !text) {
         set_error("null argument");

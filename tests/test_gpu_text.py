@@ -96,3 +96,59 @@ def test_text_with_digestion(oracle_mod):
     ix = capi.Index.from_raw(rawd, 0)
     got = ix.query_text(capi.SPX_MODE_PML, seqs, offs, gap, capi.SPX_TEXT_LENGTHS, digest=(capi.SPX_DIGEST_PROMOTED, k, w))
     assert _fill(got["text"][0], got["line_start"][0], ids) == _expect(lens, np.asarray(doffs, dtype=np.int64), ids)
+
+
+def test_text_scratch_reserved_ahead_and_two_contexts_at_once(oracle_mod):
+    """spx_query_text_reserve (round 5): the scratch of a begin / fetch pair allocated ahead -- too small, exact and generous
+    hints all give the same bytes (a hint, not a limit), for PML + docs + class and for MS.  Then two query contexts of one
+    index (spx_index_clone onto the same device) run begin / fetch from two threads at once, many times: every result is
+    the oracle's -- the sizes and counters a begin waits for are published by a kernel into page-locked host memory, and the
+    class records arrive with the text, at fetch."""
+    import threading
+    raw, text = cases.real_case(77, 12000, DNA, ndocs=4)
+    rng = np.random.default_rng(77)
+    seqs, offs = cases.reads_mixed(rng, text, DNA, 400, 300, [2])
+    ids = [b"r%d" % q for q in range(offs.size - 1)]
+    gap = np.array([len(i) + 2 for i in ids], dtype=np.uint32)
+    orc = oracle_mod.OracleIndex.from_raw(raw)
+    lens, docs = orc.pml(seqs, offs, want_docs=True)
+    want = (_expect(lens, offs, ids), _expect(docs, offs, ids))
+    f, a, b, s_ = oracle_mod.classify(lens, offs, 20, 6)
+    ix = capi.Index.from_raw(raw, 0)
+    streams = capi.SPX_TEXT_LENGTHS | capi.SPX_TEXT_DOCS
+
+    def check(handle):
+        got = handle.query_text(capi.SPX_MODE_PML, seqs, offs, gap, streams, classify=(20, 6))
+        assert _fill(got["text"][0], got["line_start"][0], ids) == want[0]
+        assert _fill(got["text"][2], got["line_start"][2], ids) == want[1]
+        assert np.array_equal(got["class"]["above"], a) and np.array_equal(got["class"]["below"], b)
+
+    for chars, reads, tb in ((16, 1, (1, 1, 1)), (int(offs[-1]), offs.size - 1, None), (4 * int(offs[-1]), 4 * offs.size, (10 ** 6, 0, 10 ** 6))):
+        ix.reserve_text(capi.SPX_MODE_PML, chars, reads, streams, classify=True, text_bytes=tb)
+        check(ix)
+    with pytest.raises(Exception):
+        ix.reserve_text(7, 100, 10)
+    # MS
+    ix.set_text(__import__("torch").from_numpy(text.copy()))
+    ix.reserve_text(capi.SPX_MODE_MS, 2 * int(offs[-1]), 2 * offs.size, capi.SPX_TEXT_LENGTHS | capi.SPX_TEXT_POINTERS)
+    w = orc.ms(seqs, offs, text=text)
+    got = ix.query_text(capi.SPX_MODE_MS, seqs, offs, gap, capi.SPX_TEXT_LENGTHS | capi.SPX_TEXT_POINTERS)
+    assert _fill(got["text"][0], got["line_start"][0], ids) == _expect(w["lengths"], offs, ids)
+    assert _fill(got["text"][1], got["line_start"][1], ids) == _expect(w["pointers"], offs, ids)
+    # two contexts, two threads
+    other = ix.clone(0)
+    errors = []
+
+    def worker(handle):
+        try:
+            for _ in range(25):
+                check(handle)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(h,)) for h in (ix, other)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:2]

@@ -45,6 +45,13 @@ print(f"  host-to-device busy (union) {busy(h2d):7.1f} ms   ({len(h2d)} copies, 
 print(f"  device-to-host busy (union) {busy(d2h):7.1f} ms   ({len(d2h)} copies)")
 print(f"  anything busy (union)       {busy(inw + h2d + d2h):7.1f} ms  -> idle {win - busy(inw + h2d + d2h):.1f} ms")
 print(f"  copies of both directions at once: {busy(h2d) + busy(d2h) - busy(h2d + d2h):.1f} ms; a kernel and a copy at once: {busy(inw) + busy(h2d + d2h) - busy(inw + h2d + d2h):.1f} ms")
+# the timeline of ~4 super-batches from the middle of the run: every copy above 100 KB and every kernel above 20 us
+mid = t0 + (t1 - t0) // 2
+ev = [(a, b, "H2D " if "HOST_TO_DEVICE" in n.upper() else "D2H ", "") for a, b, n in cp if b - a > 20000] + [(a, b, "kern", n.split("(")[0][:60]) for a, b, n in ker if b - a > 20000]
+ev = sorted(e for e in ev if mid <= e[0] < mid + 13_000_000)
+print("  timeline from the middle of the run (ms from its start; start, end, duration):")
+for a, b, kind, name in ev:
+    print(f"    {(a - mid) / 1e6:7.3f} {(b - mid) / 1e6:7.3f} {(b - a) / 1e6:6.3f}  {kind} {name}")
 big = sorted(d2h, key=lambda c: c[0] - c[1])[:5]
 print("  longest device-to-host copies (ms):", [round((c[1] - c[0]) / 1e6, 2) for c in big])
 PY
