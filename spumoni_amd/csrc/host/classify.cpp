@@ -584,9 +584,13 @@ struct OutFile {
     int fd = -1;
     uint64_t end = 0;          // logical size: everything below is final (batches complete in input order)
     uint64_t reserved = 0;     // device-text runs: where the next super-batch's share starts (OffsetOrder)
-    char* map = nullptr;       // the file's first map_size bytes as memory (MAP_SHARED), or null
-    uint64_t map_size = 0;
-    bool pinned = false;       // ... and page-locked: the device writes it
+    char* map = nullptr;       // the file's first bytes as memory (MAP_SHARED), or null: mapped_bytes of them were mapped,
+    uint64_t mapped_bytes = 0;  // and the first map_size may be written to (shrinks when the file's excess is trimmed away early)
+    std::atomic<uint64_t> map_size{0};
+    bool pinned = false;       // ... and page-locked: the device writes it -- its first pinned_size bytes (the rest of the mapping takes the
+    uint64_t pinned_size = 0;  // text through a page-locked buffer and the pool's memcpy, and its excess can be cut off beside the run)
+    std::mutex cut_mu;         // held while the file's size is cut (EarlyTrim, settle) and while a writer thread writes to it
+    bool settled = false;      // (under cut_mu) cut to its logical size: no one cuts it again
     std::string temp_path;     // prepared ahead of time under this name, renamed when the run starts
     void open(const std::string& path) {
         // A large output of an earlier run under the same name: truncating it gives its pages back synchronously
@@ -635,10 +639,12 @@ struct OutFile {
     void drop_mapping() {
         if (!map) return;
         if (pinned) (void)spx_host_unregister(map);
-        ::munmap(map, map_size);
+        ::munmap(map, mapped_bytes);
         map = nullptr;
+        mapped_bytes = 0;
         map_size = 0;
         pinned = false;
+        pinned_size = 0;
     }
     // the file ends where its last complete super-batch does (the prepared tail was an estimate; after a fatal read the
     // device may already have written later super-batches behind it)
@@ -657,6 +663,8 @@ struct OutFile {
         // the entries ahead with madvise(DONTNEED) on several threads made it slower on the GPU box, 45 -> 70-160 ms:
         // profiles/r05_early_trim_experiment.txt)
         const auto t2 = now();
+        std::lock_guard<std::mutex> g(cut_mu);
+        settled = true;
         if (::ftruncate(fd, (off_t)end) != 0) std::fprintf(stderr, "[spumoni-gpu] could not cut the output file to its size\n");
         settle_s[0] = secs(t0, t1);
         settle_s[1] = secs(t1, t2);
@@ -682,21 +690,116 @@ using Outputs = OutputFiles;
 // one that is waited for is always in some worker's hands.)
 class OffsetOrder {
 public:
-    void reserve(uint64_t seq, Outputs& out, const uint64_t bytes[NFILES], uint64_t off[NFILES]) {
+    // input: the bytes of the reads file this super-batch stands for
+    void reserve(uint64_t seq, Outputs& out, const uint64_t bytes[NFILES], uint64_t off[NFILES], uint64_t input) {
         std::unique_lock<std::mutex> g(mu_);
         cv_.wait(g, [&] { return next_ == seq; });
         for (int f = 0; f < NFILES; ++f) {
             off[f] = out.f[f].reserved;
             out.f[f].reserved += bytes[f];
         }
+        consumed_ += input;
         next_++;
         cv_.notify_all();
+    }
+    // the places handed out so far and the input they stand for, as of one moment
+    void snapshot(const Outputs& out, uint64_t used[NFILES], uint64_t& consumed) {
+        std::lock_guard<std::mutex> g(mu_);
+        for (int f = 0; f < NFILES; ++f) used[f] = out.f[f].reserved;
+        consumed = consumed_;
+    }
+    // file f's writable mapping ends at `target` from now on -- unless a place beyond it was handed out already
+    bool shrink(Outputs& out, int f, uint64_t target) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (out.f[f].reserved > target || target >= out.f[f].map_size.load()) return false;
+        out.f[f].map_size.store(target);
+        return true;
     }
 
 private:
     std::mutex mu_;
     std::condition_variable cv_;
-    uint64_t next_ = 0;
+    uint64_t next_ = 0, consumed_ = 0;
+};
+
+// The prepared tails are sized from an estimate on the generous side, and what is too much has to be given back: cutting
+// 390 MB of allocated, mapped, page-locked pages off the 4e6-read run's .pseudo_lengths took 50 ms AFTER the last byte was in
+// place -- of a 131 ms run.  Half way through the input the places handed out predict the final sizes to a few percent, so a
+// helper cuts the excess off THEN, beside the run (ftruncate takes the file's inode lock, which nothing else wants: the text
+// arrives through the mapping): the mapping's writable end moves down first, under the lock the places are handed out under
+// and only if no place beyond it has been handed out, so that later super-batches which turn out to need more take the plain
+// way (writer thread) behind the cut.  What is left for the end is the last few percent.
+class EarlyTrim {
+public:
+    EarlyTrim(OutputFiles& out, OffsetOrder& order, uint64_t input_bytes) : out_(out), order_(order), input_bytes_(std::max<uint64_t>(input_bytes, 1)) {
+        if (const char* e = std::getenv("SPUMONI_TRIM_MIN")) min_ = std::strtoull(e, nullptr, 10);  // (tests: 0 -- tiny files are trimmed too)
+        th_ = std::thread([this] { loop(); });
+    }
+    ~EarlyTrim() { finish(); }
+    void finish() {  // (joined: seconds() / trimmed_bytes() are final after this)
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    void poke() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            ++pokes_;
+        }
+        cv_.notify_all();
+    }
+    double seconds() const { return seconds_; }
+    uint64_t trimmed_bytes() const { return trimmed_; }
+
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(mu_);
+        uint64_t seen = 0;
+        int stage[NFILES] = {0, 0, 0, 0};  // 0: untouched, 1: cut at half the input, 2: cut again at 85 %
+        while (!stop_) {
+            cv_.wait(g, [&] { return stop_ || pokes_ != seen; });  // (no wait_for: gcc 11's TSan does not know pthread_cond_clockwait)
+            if (stop_) break;
+            seen = pokes_;
+            g.unlock();
+            uint64_t used[NFILES], consumed = 0;
+            order_.snapshot(out_, used, consumed);
+            const double share = std::min(1.0, (double)consumed / (double)input_bytes_);
+            for (int f = 0; f < NFILES; ++f) {
+                OutFile& of = out_.f[f];
+                if (of.fd < 0 || !of.map) continue;
+                const int want_stage = share >= 0.85 ? 2 : (share >= 0.5 ? 1 : 0);
+                if (want_stage <= stage[f]) continue;
+                stage[f] = want_stage;
+                // the predicted final size + 4 % (2 % the second time) + 16 MB, on a page boundary
+                const double predicted = (double)used[f] / share;
+                // (never into the part that is registered with the device: pinned_size)
+                const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * (want_stage == 2 ? 1.01 : 1.03)) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
+                const uint64_t before = of.map_size.load();
+                if (target + min_ >= before) continue;  // (nothing worth a system call)
+                // (cut_mu: a later super-batch that needs more than the cut leaves goes through the file's writer thread, which must
+                // not write behind the new end before the cut has happened; and a fatal exit settles the file once, for good)
+                std::lock_guard<std::mutex> cut(of.cut_mu);
+                if (of.settled || !order_.shrink(out_, f, target)) continue;
+                const auto t0 = std::chrono::steady_clock::now();
+                if (::ftruncate(of.fd, (off_t)target) != 0) { /* (the file keeps its excess until the end) */ }
+                seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                trimmed_ += before - target;
+            }
+            g.lock();
+        }
+    }
+    OutputFiles& out_;
+    OffsetOrder& order_;
+    const uint64_t input_bytes_;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+    uint64_t pokes_ = 0, trimmed_ = 0, min_ = 32u << 20;
+    double seconds_ = 0;
 };
 
 // Formats reads [lo, hi) of a super-batch into text; run by several host threads at once
@@ -1014,6 +1117,7 @@ struct Slot {
     uint64_t file_bytes[NFILES] = {};        // ... and its size there
     bool placed = false;
     uint64_t report_bytes = 0;               // bytes of its report lines (known from the ids)
+    uint64_t input_bytes = 0;                // bytes of the reads file it stands for (lines and their newlines)
     std::atomic<int> writers_left{0};
     int deferred = 0;            // 0 none, 1 FATAL_ERROR, 2 "empty after digestion" FATAL_WARNING
     std::string deferred_msg;
@@ -1169,6 +1273,8 @@ bool outputs_can_be_mapped(const RunOptions& o);
 // per GPU" -- the groups share the pool, whose size follows the devices as well (spumoni_main.cpp)
 static size_t feeders_for(size_t nworkers) { return std::max<size_t>(2, std::min<size_t>(8, nworkers / 2 + 1)); }
 static size_t slots_for(size_t nworkers) { return nworkers + feeders_for(nworkers) + 2; }  // one per worker, one per feeder, two being written
+static double pin_share();
+static uint64_t split_min_bytes();
 void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
     if (spx_device_count() <= 0) return;
     // sized from the reads file, not from the super-batch limit alone: a small file needs small blocks and few
@@ -1190,8 +1296,10 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
         if (std::getenv("SPUMONI_HOST_FORMAT")) continue;
         // (the streams' record offsets always; their text only when it will not land in the files themselves)
         const bool text_staged = !outputs_can_be_mapped(o);
+        // (... or lands in the part of a file's tail that is not registered with the device: lengths and document ids of large runs)
+        const bool upper_part = !text_staged && pin_share() < 1.0 && (double)fsize * 2.2 >= (double)split_min_bytes();
         if (!report_only) {  // lengths: "<value> " is 2-4 bytes for most values
-            if (text_staged) sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
+            if (text_staged || upper_part) sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.ms) {  // pointers: up to 13 digits
@@ -1199,7 +1307,7 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.use_doc) {
-            if (text_staged) sizes.push_back(chars * 3);
+            if (text_staged || upper_part) sizes.push_back(chars * 3);
             sizes.push_back((reads_guess + 1) * 8);
         }
     }
@@ -1254,7 +1362,17 @@ bool outputs_can_be_mapped(const RunOptions& o) {
 
 // One file's tail as memory: created under a temporary name, `size` bytes allocated (fallocate), mapped, its page table
 // entries made by a few threads, and -- the value streams -- page-locked for the device.
-static void prepare_one(OutputFiles* out, int f, const std::string& final_path, uint64_t est, bool pin) {
+static double pin_share() {
+    // The share of a value stream's prepared tail that is registered with the device.  What is registered cannot be given
+    // back while the device works (profiles/r05_early_trim_experiment.txt: the run hangs), and giving back the estimate's
+    // excess AFTER the run was a third of it; so the upper part of the tail is mapped and populated but not registered --
+    // super-batches that land there go through a page-locked buffer and the pool's memcpy (the `nopin` way), and EarlyTrim
+    // cuts what the run will not need while it runs.  1: everything registered, nothing cut early (round 5's first form).
+    if (const char* e = std::getenv("SPUMONI_PIN_SHARE")) return std::min(1.0, std::max(0.0, std::atof(e)));
+    return 0.7;
+}
+
+static void prepare_one(OutputFiles* out, int f, const std::string& final_path, uint64_t est, bool pin, double share = 1.0) {
     const auto tick = [] { return std::chrono::steady_clock::now(); };
     const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     OutFile& of = out->f[f];
@@ -1294,14 +1412,25 @@ static void prepare_one(OutputFiles* out, int f, const std::string& final_path, 
     t0 = tick();
     of.fd = fd;
     of.map = (char*)m;
+    of.mapped_bytes = size;
     of.map_size = size;
-    if (pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) of.pinned = spx_host_register(m, size) == SPX_OK;
+    if (pin && !env_is("SPUMONI_MAP_OUTPUT", "nopin")) {
+        const uint64_t psize = share >= 1.0 ? size : std::min<uint64_t>(size, ((uint64_t)((double)size * share) + 4095) & ~4095ull);
+        if (psize > 0 && spx_host_register(m, psize) == SPX_OK) {
+            of.pinned = true;
+            of.pinned_size = psize;
+        }
+    }
     std::lock_guard<std::mutex> g(g_settle_mu);
     out->prep_s[0] += s0;
     out->prep_s[1] += s1;
     out->prep_s[2] += since(t0);
 }
 
+static uint64_t split_min_bytes() {  // (below this a tail is registered as a whole: there is little to give back)
+    if (std::getenv("SPUMONI_MAP_MIN")) return 0;  // (tests: tiny files too)
+    return 256u << 20;
+}
 static uint64_t map_min_bytes() {
     // (SPUMONI_MAP_MIN / SPUMONI_MAP_FACTOR: tests map the tails of tiny files, and size them short so that a run crosses from
     // the prepared tail into plain writes)
@@ -1346,7 +1475,9 @@ void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_
     static const char* const ext[3] = {nullptr, ".pointers", ".doc_numbers"};
     for (int f = 0; f < 3; ++f) {
         if (est[f] == 0 || est[f] < map_min_bytes()) continue;
-        prepare_one(out, f, o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]), est[f], true);
+        // (the pointers stay registered as a whole: a page-locked buffer per slot for their text would be 12 bytes per character)
+        prepare_one(out, f, o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]), est[f], true,
+                    f == F_POINTERS || est[f] < split_min_bytes() ? 1.0 : pin_share());
     }
     std::lock_guard<std::mutex> g(g_settle_mu);
     out->prepare_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1409,6 +1540,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     // the run's regime (the same rule as run_on_device): the value files' text comes from the device, with its size known
     // before it is copied out -- their places are reserved; or it is formatted on the host and appended in input order.  The
     // report's lines have a size known from the ids: its places are reserved in every regime.
+    std::unique_ptr<EarlyTrim> trimmer_owner(new EarlyTrim(out, order, input.file_bytes()));
+    EarlyTrim& trimmer = *trimmer_owner;
     static const bool host_format = std::getenv("SPUMONI_HOST_FORMAT") != nullptr;
     const bool no_len_text = o.report_only && !o.ms && o.write_report;
     const uint32_t run_streams = (no_len_text ? 0u : SPX_TEXT_LENGTHS) | (o.ms ? SPX_TEXT_POINTERS : 0u) | (o.use_doc ? SPX_TEXT_DOCS : 0u);
@@ -1443,10 +1576,11 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                     if (!out.f[f].is_open()) want[f] = 0;
                     s.file_bytes[f] = want[f];
                 }
-                order.reserve(s.seq, out, want, s.file_off);
+                order.reserve(s.seq, out, want, s.file_off, s.input_bytes);
+                trimmer.poke();
                 s.placed = true;
                 for (int f = 0; f < 3; ++f)
-                    if (want[f] && out.f[f].pinned && s.file_off[f] + want[f] <= out.f[f].map_size) dest[f] = out.f[f].map + s.file_off[f];
+                    if (want[f] && out.f[f].pinned && s.file_off[f] + want[f] <= out.f[f].pinned_size) dest[f] = out.f[f].map + s.file_off[f];
             };
             if (s.sb.nreads() > 0) run_on_device(set.ix[d], o, s.sb, max_value_thr, s.res, place);
             if (!s.placed) {
@@ -1502,6 +1636,10 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
             const auto t0 = tick();
             if (by_offsets(f)) {
                 uint64_t at = s.file_off[f];
+                // (not while EarlyTrim cuts the file: see there -- and only when there is something to write: the cut takes tens of
+                // milliseconds, and a writer that waits for it holds up its slot, the feeders behind it and every worker)
+                std::unique_lock<std::mutex> cut(out.f[f].cut_mu, std::defer_lock);
+                if (!s.pieces[f].empty()) cut.lock();
                 for (const Piece& pc : s.pieces[f]) {
                     const uint64_t n = std::min<uint64_t>(pc.n, s.file_off[f] + s.file_bytes[f] - at);  // (a super-batch cut at a fatal read)
                     out.f[f].write_at(pc.p, n, at);
@@ -1568,6 +1706,8 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                 }
                 slots[(size_t)i].seq = next_seq++;
                 slots[(size_t)i].last = input_done;
+                slots[(size_t)i].input_bytes = 0;
+                for (const ReadFile::Range& r : ranges) slots[(size_t)i].input_bytes += r.bytes + (r.last - r.first);
                 seg_s += since(t0);
             }
             Slot& s = slots[(size_t)i];
@@ -1590,13 +1730,14 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     for (auto& w : writers) w.join();
     // (the files' tails were prepared from an estimate on the generous side: what is too much is given back here, ~13 ms per
     // 100 MB of allocated, mapped, page-locked pages -- profiles/r05_early_trim_experiment.txt on why not beside the run)
+    trimmer.finish();  // (joined before the files are cut)
     const double t_before_settle = since(t_stage0);
     settle_outputs(true);  // the files end where their last super-batch does
     std::fprintf(stderr, "[timing] the first super-batch reached its device after %.3f s, the last left it after %.3f s, the files were complete after %.3f s "
-                         "and cut to their sizes after %.3f s (un-registering %.3f, the cut %.3f s)\n",
+                         "and cut to their sizes after %.3f s (un-registering %.3f, the cut %.3f s; excess cut off beside the run: %.3f MB in %.3f s)\n",
                  (double)first_on_device_us.load() / 1e6, (double)last_off_device_us.load() / 1e6, t_before_settle, since(t_stage0),
                  out.f[0].settle_s[0] + out.f[1].settle_s[0] + out.f[2].settle_s[0] + out.f[3].settle_s[0],
-                 out.f[0].settle_s[2] + out.f[1].settle_s[2] + out.f[2].settle_s[2] + out.f[3].settle_s[2]);
+                 out.f[0].settle_s[2] + out.f[1].settle_s[2] + out.f[2].settle_s[2] + out.f[3].settle_s[2], (double)trimmer.trimmed_bytes() / 1e6, trimmer.seconds());
     std::fprintf(stderr, "[timing] %-22s %.3f s\n", "first read .. last byte", since(t_stage0));
     g_calls.print();
     // per-stage times (ours; the stages overlap and most are sums over threads, so they do not add up to the total)

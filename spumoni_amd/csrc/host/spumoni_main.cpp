@@ -271,8 +271,9 @@ static int run_main(int argc, char** argv) {
     o.ms = (o.result_type == 0);
     // SPUMONI_GPUS: the device of every WORKER (a host thread that feeds a device from the one queue of parsed
     // super-batches).  Two entries that name the same device are two query contexts over one copy of the index: one's
-    // copies over PCIe run under the other's kernels.  Default: "0,0"; "all": every visible device, twice.
-    o.devices = {0, 0};
+    // copies over PCIe run under the other's kernels.  Default: "0,0,0" (three keep the copy engines busy: files complete after
+    // 0.062-0.072 s against 0.076-0.081 with two, profiles/r05_cli_overlap.txt); "all": every visible device, twice.
+    o.devices = {0, 0, 0};
     if (const char* g = std::getenv("SPUMONI_GPUS")) {
         o.devices.clear();
         if (std::strcmp(g, "all") == 0) {

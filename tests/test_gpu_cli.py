@@ -470,7 +470,9 @@ def test_cli_many_small_super_batches_on_the_device(built, tmp_path, monkeypatch
 
 
 @pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
-                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin"}])
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_TRIM_MIN": "0", "SPUMONI_MAP_FACTOR": "4"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_PIN_SHARE": "1"}])
 def test_cli_output_tails_as_memory_on_the_device(built, tmp_path, monkeypatch, regime):
     """Round 5, on the device: the output files' tails prepared as memory and registered with HIP (spx_host_register on a
     MAP_SHARED mapping of the file), the text of every super-batch copied by the device into the file's pages at its place in
@@ -489,7 +491,13 @@ def test_cli_output_tails_as_memory_on_the_device(built, tmp_path, monkeypatch, 
         line = [ln for ln in err.splitlines() if "output bytes:" in ln][0]
         direct = float(line.split("output bytes:")[1].split("MB")[0])
         staged = float(line.split("pages,")[1].split("MB")[0])
-        if "SPUMONI_MAP_FACTOR" in regime:
+        if "SPUMONI_TRIM_MIN" in regime:
+            # (an estimate four times too long: the part of the tail that is not registered with the device is cut off the
+            # file beside the run -- EarlyTrim -- while the device writes the registered part)
+            cut = [ln for ln in err.splitlines() if "cut off beside the run:" in ln]
+            assert cut and float(cut[0].split("cut off beside the run:")[1].split()[0]) > 0, err[-1500:]
+            assert direct > 0, line
+        elif "SPUMONI_MAP_FACTOR" in regime:
             assert direct > 0 and staged > 0, line
         else:
             assert direct > 0 and staged == 0, line

@@ -99,14 +99,19 @@ def test_many_small_super_batches_on_three_workers(on_fake_device, tmp_path, mon
 @pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.02"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.6"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_TRIM_MIN": "0", "SPUMONI_MAP_FACTOR": "4"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_TRIM_MIN": "0", "SPUMONI_PIN_SHARE": "0.2"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_PIN_SHARE": "1"},
                                     {"SPUMONI_MAP_OUTPUT": "0"}])
 def test_output_files_tails_as_memory(on_fake_device, tmp_path, monkeypatch, oracle_mod, regime):
     """Round 5: the output files' tails are prepared as memory while the index loads (allocated, mapped, registered with the
     device) and a super-batch's text lands in the file's pages at its place in input order -- no write().  The same bytes as
     the oracle harness when every tail is mapped (SPUMONI_MAP_MIN=1: also for these tiny files), when the estimate is short
     and the run crosses into plain writes after a few super-batches (SPUMONI_MAP_FACTOR), when the mapping is not
-    registered and the pool copies the text in (nopin), and with the mechanism off; a fatal read cuts the files where the
-    reference stops although later super-batches are already in the mapping."""
+    registered and the pool copies the text in (nopin), when the estimate is four times too long and the excess is cut off
+    beside the run (EarlyTrim; SPUMONI_TRIM_MIN=0: for tiny files too), when only a fifth of the tail is registered with the
+    device (SPUMONI_PIN_SHARE) or all of it, and with the mechanism off; a fatal read cuts the files where the reference
+    stops although later super-batches are already in the mapping."""
     T = _cli()
     for k, v in regime.items():
         monkeypatch.setenv(k, v)
@@ -119,6 +124,9 @@ def test_output_files_tails_as_memory(on_fake_device, tmp_path, monkeypatch, ora
         assert "its tail was prepared as memory" not in err
     else:
         assert "its tail was prepared as memory" in err, err[-1500:]
+    if regime.get("SPUMONI_MAP_FACTOR") == "4":
+        cut = [ln for ln in err.splitlines() if "cut off beside the run:" in ln]
+        assert cut and float(cut[0].split("cut off beside the run:")[1].split()[0]) > 0, err[-1500:]
     T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "60"], "-M")
     (tmp_path / "a").mkdir()
     (tmp_path / "b").mkdir()
@@ -224,10 +232,11 @@ def test_cli_differential_fuzz_against_the_oracle_harness(on_fake_device, tmp_pa
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
-                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.5"}])
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.5"},
+                                    {"SPUMONI_MAP_MIN": "1", "SPUMONI_TRIM_MIN": "0", "SPUMONI_MAP_FACTOR": "2"}])
 def test_cli_differential_fuzz_with_the_output_tails_as_memory(on_fake_device, tmp_path, regime):
     """The same fuzz, thirty other seeds, with the round-5 drain in each of its regimes (the files' tails mapped + registered,
-    an estimate that runs out mid-run, mapped without registration): fatal reads must still cut every file where the
+    an estimate that runs out mid-run, mapped without registration, the excess cut off beside the run): fatal reads must still cut every file where the
     reference stops.  (6 000 further seeds, ASan and TSan builds: DESIGN.md 6.)"""
     env = dict(os.environ, FAKE_DEVICE_DIR=on_fake_device, CLI_FUZZ_DIR=str(tmp_path / "fuzz"), **regime)
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "cli_fuzz_cpu.py"), "30", "500"], capture_output=True, text=True, env=env)

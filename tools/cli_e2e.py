@@ -73,7 +73,7 @@ def run(tag, reads, extra_env):
 
 
 run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
-run("flat-layout cache (default: SPUMONI_GPUS=0,0 -- two workers, one copy of the index)", f"{d}/reads.fa", {})
+run("flat-layout cache (default: SPUMONI_GPUS=0,0,0 -- three workers, one copy of the index)", f"{d}/reads.fa", {})
 quick = os.environ.get("E2E_QUICK") is not None  # (only the first two runs of the PML block)
 run("flat-layout cache, again", f"{d}/reads.fa", {})
 if not quick:
@@ -86,9 +86,10 @@ if not quick:
     run("SPUMONI_MAP_OUTPUT=0 (plain writes: one pwrite stream per file)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "0"})
     run("SPUMONI_MAP_OUTPUT=nopin (tails mapped, not registered: the pool copies the text in)", f"{d}/reads.fa", {"SPUMONI_MAP_OUTPUT": "nopin"})
     run("SPUMONI_MAP_FACTOR=0.5 (the estimate is short: half the file goes through the writer thread)", f"{d}/reads.fa", {"SPUMONI_MAP_FACTOR": "0.5"})
+    run("SPUMONI_PIN_SHARE=1 (the whole tail registered with the device, the estimate's excess cut at the end: the round's first form)", f"{d}/reads.fa", {"SPUMONI_PIN_SHARE": "1"})
     run("the default again", f"{d}/reads.fa", {})
     run("SPUMONI_GPUS=0 (one worker)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0"})
-    run("SPUMONI_GPUS=0,0,0 (three workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0,0"})
+    run("SPUMONI_GPUS=0,0 (two workers on one device)", f"{d}/reads.fa", {"SPUMONI_GPUS": "0,0"})
     for mb in (8, 16, 32, 128):
         run(f"SPUMONI_SUPER_BATCH={mb} MB", f"{d}/reads.fa", {"SPUMONI_SUPER_BATCH": str(mb << 20)})
     run("SPUMONI_REPORT_ONLY=1", f"{d}/reads.fa", {"SPUMONI_REPORT_ONLY": "1"})
