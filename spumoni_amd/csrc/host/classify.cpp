@@ -724,11 +724,13 @@ private:
 
 // The prepared tails are sized from an estimate on the generous side, and what is too much has to be given back: cutting
 // 390 MB of allocated, mapped, page-locked pages off the 4e6-read run's .pseudo_lengths took 50 ms AFTER the last byte was in
-// place -- of a 131 ms run.  Half way through the input the places handed out predict the final sizes to a few percent, so a
+// place -- of a 131 ms run.  A quarter of the way through the input the places handed out predict the final sizes to a few percent, so a
 // helper cuts the excess off THEN, beside the run (ftruncate takes the file's inode lock, which nothing else wants: the text
 // arrives through the mapping): the mapping's writable end moves down first, under the lock the places are handed out under
 // and only if no place beyond it has been handed out, so that later super-batches which turn out to need more take the plain
-// way (writer thread) behind the cut.  What is left for the end is the last few percent.
+// way (writer thread) behind the cut.  What is left for the end is the last few percent.  Only the part of a tail that is NOT
+// registered with the device is ever cut this way (OutFile::pinned_size, pin_share()): cutting registered pages off under live
+// queues hung the run (profiles/r05_early_trim_experiment.txt).
 class EarlyTrim {
 public:
     EarlyTrim(OutputFiles& out, OffsetOrder& order, uint64_t input_bytes) : out_(out), order_(order), input_bytes_(std::max<uint64_t>(input_bytes, 1)) {
@@ -758,7 +760,7 @@ private:
     void loop() {
         std::unique_lock<std::mutex> g(mu_);
         uint64_t seen = 0;
-        int stage[NFILES] = {0, 0, 0, 0};  // 0: untouched, 1: cut at half the input, 2: cut again at 85 %
+        int stage[NFILES] = {0, 0, 0, 0};  // 0: untouched, 1: cut at a quarter of the input, 2: cut again at 70 %
         while (!stop_) {
             cv_.wait(g, [&] { return stop_ || pokes_ != seen; });  // (no wait_for: gcc 11's TSan does not know pthread_cond_clockwait)
             if (stop_) break;
@@ -770,13 +772,16 @@ private:
             for (int f = 0; f < NFILES; ++f) {
                 OutFile& of = out_.f[f];
                 if (of.fd < 0 || !of.map) continue;
-                const int want_stage = share >= 0.85 ? 2 : (share >= 0.5 ? 1 : 0);
+                // (a quarter of the input in: the cut of a few hundred MB takes ~40 ms and should be over before the run is -- started
+                // at half the input it ended 10-20 ms AFTER the last super-batch, and the run waited for it; the second, small
+                // cut at 70 %)
+                const int want_stage = share >= 0.7 ? 2 : (share >= 0.25 ? 1 : 0);
                 if (want_stage <= stage[f]) continue;
                 stage[f] = want_stage;
                 // the predicted final size + 4 % (2 % the second time) + 16 MB, on a page boundary
                 const double predicted = (double)used[f] / share;
                 // (never into the part that is registered with the device: pinned_size)
-                const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * (want_stage == 2 ? 1.01 : 1.03)) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
+                const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * (want_stage == 2 ? 1.015 : 1.05)) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
                 const uint64_t before = of.map_size.load();
                 if (target + min_ >= before) continue;  // (nothing worth a system call)
                 // (cut_mu: a later super-batch that needs more than the cut leaves goes through the file's writer thread, which must
@@ -1271,7 +1276,11 @@ void fill_slot(Pool& pool, const ReadFile& input, const std::vector<ReadFile::Ra
 bool outputs_can_be_mapped(const RunOptions& o);
 // feeders: two for a device's two workers, one more per further device (eight at most): SURVEY 8(e)'s "one feeder thread group
 // per GPU" -- the groups share the pool, whose size follows the devices as well (spumoni_main.cpp)
-static size_t feeders_for(size_t nworkers) { return std::max<size_t>(2, std::min<size_t>(8, nworkers / 2 + 1)); }
+static size_t feeders_for(size_t nworkers) {
+    static const int forced = std::getenv("SPUMONI_FEEDERS") ? std::atoi(std::getenv("SPUMONI_FEEDERS")) : 0;  // (A/B runs)
+    if (forced > 0) return (size_t)std::min(forced, 8);
+    return std::max<size_t>(2, std::min<size_t>(8, nworkers / 2 + 1));
+}
 static size_t slots_for(size_t nworkers) { return nworkers + feeders_for(nworkers) + 2; }  // one per worker, one per feeder, two being written
 static double pin_share();
 static uint64_t split_min_bytes();
