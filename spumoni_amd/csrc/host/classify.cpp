@@ -1281,7 +1281,7 @@ static size_t feeders_for(size_t nworkers) {
     if (forced > 0) return (size_t)std::min(forced, 8);
     return std::max<size_t>(2, std::min<size_t>(8, nworkers / 2 + 1));
 }
-static size_t slots_for(size_t nworkers) { return 2 * nworkers + feeders_for(nworkers) + 2; }  // one per worker and one per finisher, one per feeder, two being written
+static size_t slots_for(size_t nworkers) { return nworkers + feeders_for(nworkers) + 2; }  // one per worker, one per feeder, two being written
 static double pin_share();
 static uint64_t split_min_bytes();
 void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
@@ -1564,27 +1564,6 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     std::atomic<uint64_t> next_seq_to_run{0};
     std::atomic<int64_t> first_on_device_us{-1}, last_off_device_us{0};
     auto us_since_start = [&] { return (int64_t)(since(t_stage0) * 1e6); };
-    // What is left of a super-batch once its text is in place -- the ">id" lines into their gaps, the report's lines at their
-    // place -- is host work on the pool (1-2 ms): done by a thread beside the worker, so that the worker's next super-batch is on
-    // its way to the device meanwhile (SPUMONI_FINISH_INLINE=1: on the worker's own thread, the form before).
-    static const bool finish_inline = std::getenv("SPUMONI_FINISH_INLINE") != nullptr;
-    std::vector<SlotQueue> finish_q(nworkers);
-    auto finish_slot = [&](size_t d, int i) {
-        Slot& s = slots[(size_t)i];
-        const auto t1 = tick();
-        finish_batch(pool, o, out, s.sb, s.res, s.chunks, s.file_off, s.pieces);
-        for (int f = 0; f < NFILES; ++f) {
-            uint64_t staged = 0;
-            for (const Piece& pc : s.pieces[f]) staged += pc.n;
-            staged_bytes += staged;
-            if (by_offsets(f)) direct_bytes += s.file_bytes[f] - std::min(staged, s.file_bytes[f]);
-        }
-        dev_finish[d] += since(t1);
-        dev_batches[d]++;
-        last_off_device_us.store(us_since_start());
-        s.writers_left.store(nfiles_open);
-        done.put(s.seq, i);
-    };
     auto device_worker = [&](size_t d) {
         for (;;) {
             const uint64_t seq = next_seq_to_run.fetch_add(1);
@@ -1638,24 +1617,23 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
                     }
             }
             dev_busy[d] += since(t0);
-            if (finish_inline)
-                finish_slot(d, i);
-            else
-                finish_q[d].push(i);  // (the headers and the report lines are its finisher's: the worker turns to the next super-batch)
+            const auto t1 = tick();
+            finish_batch(pool, o, out, s.sb, s.res, s.chunks, s.file_off, s.pieces);
+            for (int f = 0; f < NFILES; ++f) {
+                uint64_t staged = 0;
+                for (const Piece& pc : s.pieces[f]) staged += pc.n;
+                staged_bytes += staged;
+                if (by_offsets(f)) direct_bytes += s.file_bytes[f] - std::min(staged, s.file_bytes[f]);
+            }
+            dev_finish[d] += since(t1);
+            dev_batches[d]++;
+            last_off_device_us.store(us_since_start());
+            s.writers_left.store(nfiles_open);
+            done.put(s.seq, i);
         }
-        if (!finish_inline) finish_q[d].push(-1);
     };
-    auto finisher = [&](size_t d) {
-        for (;;) {
-            const int i = finish_q[d].pop();
-            if (i < 0) break;
-            finish_slot(d, i);
-        }
-    };
-    std::vector<std::thread> workers, finishers;
+    std::vector<std::thread> workers;
     for (size_t d = 0; d < nworkers; ++d) workers.emplace_back(device_worker, d);
-    if (!finish_inline)
-        for (size_t d = 0; d < nworkers; ++d) finishers.emplace_back(finisher, d);
     // ---- writers: one per file, in input order.  The last one through with a super-batch makes it final (the files' logical
     // ends move), raises what the reference would have stopped at -- after every file holds everything before it -- and
     // gives the slot back.
@@ -1758,7 +1736,6 @@ size_t classify_reads(IndexSet& set, const RunOptions& o, ReadFile* preloaded, O
     feeder(0);
     for (auto& t : feeders) t.join();
     for (auto& w : workers) w.join();
-    for (auto& w : finishers) w.join();
     for (auto& w : writers) w.join();
     // (the files' tails were prepared from an estimate on the generous side: what is too much is given back here, ~13 ms per
     // 100 MB of allocated, mapped, page-locked pages -- profiles/r05_early_trim_experiment.txt on why not beside the run)

@@ -10,7 +10,7 @@ E2E_ONLY_SETUP=1 timeout 600 python tools/cli_e2e.py > $out/setup.txt 2>&1
 d=/dev/shm/e2e
 SPUMONI_CACHE=write timeout 120 spumoni_amd/bin/spumoni run -r $d/ref -p $d/reads.fa -P -c -n > /dev/null 2>&1
 cp $d/reads.fa.pseudo_lengths $d/want.pseudo_lengths; cp $d/reads.fa.report $d/want.report
-for rep in 1 2 3; do
+for rep in 1 2 3 4; do
   for mode in "X=1" "SPUMONI_PIN_SHARE=1" "SPUMONI_GPUS=0,0" "SPUMONI_REPORT_ONLY=1"; do
     echo "== rep $rep $mode"
     env $mode timeout 20 spumoni_amd/bin/spumoni run -r $d/ref -p $d/reads.fa -P -c -n 2>&1 | sed 's/\x1b\[[0-9;]*m//g' | grep -E "first super-batch|output bytes|Finished processing"
