@@ -760,7 +760,7 @@ private:
     void loop() {
         std::unique_lock<std::mutex> g(mu_);
         uint64_t seen = 0;
-        int stage[NFILES] = {0, 0, 0, 0};  // 0: untouched, 1: cut at a quarter of the input, 2: cut again at 70 %
+        int stage[NFILES] = {0, 0, 0, 0};  // 0: untouched, 1: cut at a sixth of the input, 2: cut again at 70 %
         while (!stop_) {
             cv_.wait(g, [&] { return stop_ || pokes_ != seen; });  // (no wait_for: gcc 11's TSan does not know pthread_cond_clockwait)
             if (stop_) break;
@@ -769,30 +769,39 @@ private:
             uint64_t used[NFILES], consumed = 0;
             order_.snapshot(out_, used, consumed);
             const double share = std::min(1.0, (double)consumed / (double)input_bytes_);
+            // (the files side by side: every inode has its own lock, and MS mode has two large ones to cut)
+            std::vector<std::thread> cuts;
+            std::mutex sum_mu;
             for (int f = 0; f < NFILES; ++f) {
                 OutFile& of = out_.f[f];
                 if (of.fd < 0 || !of.map) continue;
-                // (a quarter of the input in: the cut of a few hundred MB takes ~40 ms and should be over before the run is -- started
-                // at half the input it ended 10-20 ms AFTER the last super-batch, and the run waited for it; the second, small
-                // cut at 70 %)
-                const int want_stage = share >= 0.7 ? 2 : (share >= 0.25 ? 1 : 0);
+                // (a sixth of the input in: the cut of a few hundred MB takes 40-80 ms and should be over before the run is --
+                // started at half the input it ended 10-20 ms AFTER the last super-batch, and the run waited for it; the second,
+                // small cut at 70 %)
+                const int want_stage = share >= 0.7 ? 2 : (share >= 0.16 ? 1 : 0);
                 if (want_stage <= stage[f]) continue;
                 stage[f] = want_stage;
-                // the predicted final size + 4 % (2 % the second time) + 16 MB, on a page boundary
+                // the predicted final size + 5 % (1.5 % the second time) + 8 MB, on a page boundary
                 const double predicted = (double)used[f] / share;
                 // (never into the part that is registered with the device: pinned_size)
                 const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * (want_stage == 2 ? 1.015 : 1.05)) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
                 const uint64_t before = of.map_size.load();
                 if (target + min_ >= before) continue;  // (nothing worth a system call)
-                // (cut_mu: a later super-batch that needs more than the cut leaves goes through the file's writer thread, which must
-                // not write behind the new end before the cut has happened; and a fatal exit settles the file once, for good)
-                std::lock_guard<std::mutex> cut(of.cut_mu);
-                if (of.settled || !order_.shrink(out_, f, target)) continue;
-                const auto t0 = std::chrono::steady_clock::now();
-                if (::ftruncate(of.fd, (off_t)target) != 0) { /* (the file keeps its excess until the end) */ }
-                seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                trimmed_ += before - target;
+                cuts.emplace_back([this, f, target, before, &sum_mu] {
+                    OutFile& of = out_.f[f];
+                    // (cut_mu: a later super-batch that needs more than the cut leaves goes through the file's writer thread, which
+                    // must not write behind the new end before the cut has happened; and a fatal exit settles the file once, for good)
+                    std::lock_guard<std::mutex> cut(of.cut_mu);
+                    if (of.settled || !order_.shrink(out_, f, target)) return;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (::ftruncate(of.fd, (off_t)target) != 0) { /* (the file keeps its excess until the end) */ }
+                    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    std::lock_guard<std::mutex> sg(sum_mu);
+                    seconds_ = std::max(seconds_, 0.0) + dt;
+                    trimmed_ += before - target;
+                });
             }
+            for (auto& t : cuts) t.join();
             g.lock();
         }
     }
@@ -1311,8 +1320,8 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
             if (text_staged || upper_part) sizes.push_back(chars * 3 + std::min<size_t>(8u << 20, chars));
             sizes.push_back((reads_guess + 1) * 8);
         }
-        if (o.ms) {  // pointers: up to 13 digits
-            if (text_staged) sizes.push_back(chars * 12);
+        if (o.ms) {  // pointers: up to 13 digits (MS runs take 8 MB super-batches by default: 96 MB per slot)
+            if (text_staged || upper_part) sizes.push_back(chars * 12);
             sizes.push_back((reads_guess + 1) * 8);
         }
         if (o.use_doc) {
@@ -1484,9 +1493,8 @@ void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_
     static const char* const ext[3] = {nullptr, ".pointers", ".doc_numbers"};
     for (int f = 0; f < 3; ++f) {
         if (est[f] == 0 || est[f] < map_min_bytes()) continue;
-        // (the pointers stay registered as a whole: a page-locked buffer per slot for their text would be 12 bytes per character)
         prepare_one(out, f, o.pattern_file + (f == F_LENGTHS ? (o.ms ? ".lengths" : ".pseudo_lengths") : ext[f]), est[f], true,
-                    f == F_POINTERS || est[f] < split_min_bytes() ? 1.0 : pin_share());
+                    est[f] < split_min_bytes() ? 1.0 : pin_share());
     }
     std::lock_guard<std::mutex> g(g_settle_mu);
     out->prepare_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -296,6 +296,9 @@ static int run_main(int argc, char** argv) {
     if (const char* t = std::getenv("SPUMONI_REPORT_ONLY")) o.report_only = o.write_report && !o.ms && std::atoi(t) != 0;
     // characters of reads per super-batch (32 MB; tests: a few thousand, so that a small input runs as many super-batches
     // through the queue, the workers and the ordered writer)
+    // (MS mode writes ~13 bytes of text per character where PML writes ~2.5: a quarter of the characters is the same bytes per
+    // super-batch, and the page-locked buffers of the slots -- 12 bytes per character for the pointers -- stay small)
+    if (o.ms) o.super_batch_chars = 8u << 20;
     if (const char* t = std::getenv("SPUMONI_SUPER_BATCH")) o.super_batch_chars = std::max<size_t>(1000, std::strtoull(t, nullptr, 10));
     // -t: the reference's helper threads walk the index; here the GPU does, and the threads
     // format the output text instead (default: up to 16 of the available cores)
