@@ -797,7 +797,7 @@ private:
                     if (::ftruncate(of.fd, (off_t)target) != 0) { /* (the file keeps its excess until the end) */ }
                     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     std::lock_guard<std::mutex> sg(sum_mu);
-                    seconds_ = std::max(seconds_, 0.0) + dt;
+                    seconds_ += dt;  // (summed over the files: they are cut side by side)
                     trimmed_ += before - target;
                 });
             }

@@ -182,7 +182,7 @@ __global__ void k_publish(uint64_t* dst, PubSrc src) {
 }
 static int publish(spx_index* ix, const PubSrc& src, hipStream_t st) {
     if (!ix->h_pub) {
-        SPX_HIP(hipHostMalloc((void**)&ix->h_pub, 64 * sizeof(uint64_t), hipHostMallocMapped));
+        SPX_HIP(hipHostMalloc((void**)&ix->h_pub, 64 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));  // (coherent whatever HIP_HOST_COHERENT says)
         SPX_HIP(hipHostGetDevicePointer((void**)&ix->h_pub_dev, ix->h_pub, 0));
     }
     k_publish<<<1, 64, 0, st>>>(ix->h_pub_dev, src);
@@ -1386,8 +1386,8 @@ int spx_query_text_reserve(spx_index* ix, int mode, int digest_kind, uint32_t k,
         set_error("spx_query_text_reserve: index and a mode");
         return SPX_E_ARG;
     }
+    std::lock_guard<std::mutex> hg(ix->host_mu);  // (the order every host-buffer query takes them in: host_mu, then mu)
     std::lock_guard<std::mutex> g(ix->mu);
-    std::lock_guard<std::mutex> hg(ix->host_mu);
     SPX_HIP(hipSetDevice(ix->device));
     hipStream_t st = nullptr;
     int rc;
