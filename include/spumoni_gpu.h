@@ -325,6 +325,8 @@ int spx_digest_query_batch_device16(spx_index *ix, int mode, int kind, uint32_t 
  * wavefront, 0 = automatic; 1 = the one-wavefront-per-read mapping of SURVEY 7.1,
  * kept as a measurable experiment -- see DESIGN.md 4.1)                        */
 /* "minimizer_charhash": see the digestion section above                        */
+/* "blocking_sync" 1: spx_query_text_begin / _fetch sleep on an event while they wait for the device instead of spinning on
+ * their stream -- for processes that keep several query contexts busy from as many threads and need the cores (0: spin)     */
 int spx_set_option(spx_index *ix, const char *key, int64_t value);
 
 #ifdef __cplusplus

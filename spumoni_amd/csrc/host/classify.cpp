@@ -184,6 +184,9 @@ void IndexSet::load(const RunOptions& o) {
         if (!ix[i]) fatal_error("%s", spx_last_error());
         std::fprintf(stderr, "[timing] worker %zu: a second query context on device %d (shares the arrays of worker %zu)\n", i, devs[i], src);
     }
+    // (the workers sleep while they wait for the device: the cores are the pool's -- SPUMONI_SPIN=1: they spin, the form before)
+    if (!std::getenv("SPUMONI_SPIN"))
+        for (size_t i = 0; i < nwork; ++i) (void)spx_set_option(ix[i], "blocking_sync", 1);
     // every worker's device scratch for a full super-batch, now: the first super-batch of each worker otherwise allocates it
     // inside the timed run (10 ms alone, 17-20 ms with two or three workers of one device queueing for the allocator), and a
     // buffer that grows mid-run is freed first, which synchronises the whole device (profiles/r05_cli_overlap.txt)

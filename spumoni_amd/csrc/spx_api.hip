@@ -126,6 +126,7 @@ void spx_index_free(spx_index* ix) {
     if (ix->counters) (void)hipFree(ix->counters);
     if (ix->ctx_stream) (void)hipStreamDestroy(ix->ctx_stream);
     if (ix->h_pub) (void)hipHostFree(ix->h_pub);
+    if (ix->ev_wait) (void)hipEventDestroy(ix->ev_wait);
     SPX_FT("stream destroyed");
     for (auto& st : ix->pipe_s)
         if (st) (void)hipStreamDestroy(st);
@@ -164,6 +165,18 @@ static void default_charhash(uint8_t out[4]) {
 static int ctx_stream_of(spx_index* ix, hipStream_t* out) {
     if (!ix->ctx_stream) SPX_HIP(hipStreamCreateWithFlags(&ix->ctx_stream, hipStreamNonBlocking));
     *out = ix->ctx_stream;
+    return SPX_OK;
+}
+
+// Waiting for the handle's stream: spinning (hipStreamSynchronize: lowest latency) or, "blocking_sync", asleep on an event.
+static int ctx_wait(spx_index* ix, hipStream_t st) {
+    if (!ix->blocking_sync) {
+        SPX_HIP(hipStreamSynchronize(st));
+        return SPX_OK;
+    }
+    if (!ix->ev_wait) SPX_HIP(hipEventCreateWithFlags(&ix->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+    SPX_HIP(hipEventRecord(ix->ev_wait, st));
+    SPX_HIP(hipEventSynchronize(ix->ev_wait));
     return SPX_OK;
 }
 
@@ -539,6 +552,10 @@ int spx_set_option(spx_index* ix, const char* key, int64_t value) {
         return SPX_E_ARG;
     }
     std::lock_guard<std::mutex> g(ix->mu);
+    if (!strcmp(key, "blocking_sync")) {  // 1: spx_query_text_begin / _fetch sleep while they wait for the device (several
+        ix->blocking_sync = value != 0;    // query contexts of one process: a core per spinning waiter is a core less for the host's work)
+        return SPX_OK;
+    }
     if (!strcmp(key, "waves_per_cu")) {
         ix->waves_per_cu = (int)value;
         return SPX_OK;
@@ -1252,7 +1269,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
         {
             PubSrc ps{{(const uint64_t*)ddo + nreads, nullptr, nullptr, nullptr}, nullptr, 0};
             if ((rc = publish(ix, ps, st)) != SPX_OK) return rc;
-            SPX_HIP(hipStreamSynchronize(st));
+            if ((rc = ctx_wait(ix, st)) != SPX_OK) return rc;
             total = ix->h_pub[0];
         }
         wseq = (const uint8_t*)dd;
@@ -1294,7 +1311,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
             if (vals[i]) ps.one[i] = (const uint64_t*)ls[i] + nreads;
         if ((rc = publish(ix, ps, st)) != SPX_OK) return rc;
         mark(3);
-        SPX_HIP(hipStreamSynchronize(st));
+        if ((rc = ctx_wait(ix, st)) != SPX_OK) return rc;
         if (phase_trace) {
             float a = 0, b = 0, c = 0;
             (void)hipEventElapsedTime(&a, pe[0], pe[1]);
@@ -1361,7 +1378,10 @@ int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) 
     if (ix->text_cls_host)
         SPX_HIP(hipMemcpyAsync(ix->text_cls_host, ix->scratch[5].p, ix->text_nreads * sizeof(spx_class), hipMemcpyDeviceToHost, st));
     if (phase_trace) (void)hipEventRecord(fe[1], st);
-    SPX_HIP(hipStreamSynchronize(st));
+    {
+        const int rc = ctx_wait(ix, st);
+        if (rc != SPX_OK) return rc;
+    }
     if (phase_trace) {
         float a = 0;
         (void)hipEventElapsedTime(&a, fe[0], fe[1]);

@@ -205,6 +205,8 @@ struct spx_index {
     // a kernel into page-locked host memory, NOT copied -- a device-to-host copy of 8 bytes queues on the copy engine behind
     // whatever another query context of the same device is copying out (1.4 ms per super-batch of text), which made
     // spx_query_text_begin of one worker wait for spx_query_text_fetch of the other (profiles/r05_cli_overlap.txt).
+    int blocking_sync = 0;          // "blocking_sync" option: the host-buffer text queries wait for their stream on an event with
+    hipEvent_t ev_wait = nullptr;   // hipEventBlockingSync (the thread sleeps) instead of hipStreamSynchronize (it spins on a core)
     uint64_t* h_pub = nullptr;      // host address
     uint64_t* h_pub_dev = nullptr;  // the same memory as the device sees it
     int chunk_mode = 0;   // "chunk_mode" option: 0 automatic, 1 never, 2 always
