@@ -135,8 +135,9 @@ def test_text_scratch_reserved_ahead_and_two_contexts_at_once(oracle_mod):
     got = ix.query_text(capi.SPX_MODE_MS, seqs, offs, gap, capi.SPX_TEXT_LENGTHS | capi.SPX_TEXT_POINTERS)
     assert _fill(got["text"][0], got["line_start"][0], ids) == _expect(w["lengths"], offs, ids)
     assert _fill(got["text"][1], got["line_start"][1], ids) == _expect(w["pointers"], offs, ids)
-    # two contexts, two threads
+    # two contexts, two threads; one of them sleeps on an event while it waits for the device ("blocking_sync"), one spins
     other = ix.clone(0)
+    other.set_option("blocking_sync", 1)
     errors = []
 
     def worker(handle):
