@@ -46,10 +46,10 @@ except Exception as e:
     print("bench line unreadable:", e)
 PY
 done
-# ---- the CLI: one queue of parsed super-batches, two workers per device, the index copied device to device ----
+# ---- the CLI: one queue of parsed super-batches, three workers on one device / two per device on all, the index copied device to device ----
 d=${E2E_DIR:-/dev/shm/e2e8}
 E2E_DIR=$d E2E_READS=${E2E_READS:-10000000} E2E_CPU_READS=20000 E2E_ONLY_SETUP=1 timeout 1800 python tools/cli_e2e.py > "$out/cli_setup.txt" 2>&1
-for gpus in 0,0 all; do
+for gpus in 0,0,0 all; do
   [ "$gpus" = all ] && [ "$ngpu" -lt 2 ] && continue
   for mode in "" "SPUMONI_REPORT_ONLY=1"; do
     echo "== SPUMONI_GPUS=$gpus $mode"
