@@ -1484,7 +1484,17 @@ void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_
     // w - k + 1 k-mers (k letters each with -a)
     double v = 1.0;
     if (digest) v = std::min(1.0, 2.2 / (double)(o.w - o.k + 2) * (o.use_dna_letters ? (double)o.k : 1.0));
-    const double factor = map_factor(), fb = (double)reads_file_bytes;
+    double fb = (double)reads_file_bytes;
+    {
+        // (a FASTQ file is half qualities: batch_loader.cpp:30-38 tells the formats apart by the first character, so does this)
+        char first = 0;
+        const int rfd = ::open(o.pattern_file.c_str(), O_RDONLY);
+        if (rfd >= 0) {
+            if (::read(rfd, &first, 1) == 1 && first == '@') fb *= 0.52;
+            ::close(rfd);
+        }
+    }
+    const double factor = map_factor();
     // bytes per value: lengths "<1-3 digits> ", pointers "<up to 13 digits> ", document ids "<1-3 digits> "; + the ">id" lines
     uint64_t est[3] = {0, 0, 0};
     const bool report_only = o.report_only && !o.ms && o.write_report;

@@ -101,6 +101,41 @@ if not quick:
     run("-t 4 (a pool of four)", f"{d}/reads.fa", {"E2E_EXTRA": "-t 4"})
     run("-t 4, report only", f"{d}/reads.fa", {"E2E_EXTRA": "-t 4", "SPUMONI_REPORT_ONLY": "1"})
     run("-t 2, report only", f"{d}/reads.fa", {"E2E_EXTRA": "-t 2", "SPUMONI_REPORT_ONLY": "1"})
+# ---- FASTQ input: the same reads with qualities (the output tails are sized for half the file: batch_loader.cpp:30-38) ----
+if os.environ.get("E2E_FASTQ", "1") != "0" and not quick:
+    nq = min(nreads, 2000000)
+    rows = seqs.reshape(nreads, m)
+    qual = b"I" * m
+    write_fasta(f"{d}/half.fa", 0, nq)
+    with open(f"{d}/halfq.fa", "wb") as f:
+        for i in range(0, nq, 100000):
+            f.write(b"".join(b"@read_%d\n" % j + rows[j].tobytes() + b"\n+\n" + qual + b"\n" for j in range(i, min(nq, i + 100000))))
+    saved = nreads
+    nreads_for_rate = nq
+
+    def run_q(tag, reads):
+        t0 = time.time()
+        r = subprocess.run([f"{ROOT}/spumoni_amd/bin/spumoni", "run", "-r", f"{d}/ref", "-p", reads, "-P", "-c", "-n"], capture_output=True)
+        dt = time.time() - t0
+        err = r.stderr.decode().replace("\033[32m", "").replace("\033[0m", "")
+        assert r.returncode == 0, err
+        import re
+        secs = [float(x) for x in re.findall(r"done\.\s+\(([0-9.]+) sec\)", err)]
+        print(f"== {tag}: {dt:.2f}s wall; loading the index {secs[0]:.3f}s, processing the patterns {secs[1]:.3f}s = {nq/max(secs[1],1e-9)/1e6:.2f} M reads/s")
+        for l in err.splitlines():
+            if "first super-batch" in l or "output bytes" in l:
+                print("   ", l.strip())
+        sys.stdout.flush()
+
+    run_q(f"FASTA, {nq} reads", f"{d}/half.fa")
+    run_q(f"FASTQ content (in a file named .fa: the reference accepts the content, not the extension), the same {nq} reads with qualities", f"{d}/halfq.fa")
+    for e in (".pseudo_lengths", ".report"):
+        same = subprocess.run(["cmp", f"{d}/half.fa{e}", f"{d}/halfq.fa{e}"]).returncode == 0
+        print(f"   cmp {e} (FASTA against FASTQ input): {'identical' if same else 'DIFFERENT'}", flush=True)
+    for f_ in ("half.fa", "halfq.fa"):
+        for e in ("", ".pseudo_lengths", ".report"):
+            if os.path.exists(f"{d}/{f_}{e}"):
+                os.remove(f"{d}/{f_}{e}")
 # ---- MS mode: three output files side by side (lengths, pointers, report) ----
 if os.environ.get("E2E_MS", "1") != "0":
     dm = d + "/ms"; os.makedirs(dm, exist_ok=True)
