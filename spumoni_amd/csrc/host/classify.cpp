@@ -702,13 +702,16 @@ public:
             out.f[f].reserved += bytes[f];
         }
         consumed_ += input;
+        if (input >= 4096)  // (the densest super-batch so far, per file: how far a later one may lie above the mean)
+            for (int f = 0; f < NFILES; ++f) densest_[f] = std::max(densest_[f], (double)bytes[f] / (double)input);
         next_++;
         cv_.notify_all();
     }
-    // the places handed out so far and the input they stand for, as of one moment
-    void snapshot(const Outputs& out, uint64_t used[NFILES], uint64_t& consumed) {
+    // the places handed out so far and the input they stand for, as of one moment; densest[f]: the most output bytes per input
+    // byte any one super-batch has asked for
+    void snapshot(const Outputs& out, uint64_t used[NFILES], uint64_t& consumed, double densest[NFILES]) {
         std::lock_guard<std::mutex> g(mu_);
-        for (int f = 0; f < NFILES; ++f) used[f] = out.f[f].reserved;
+        for (int f = 0; f < NFILES; ++f) used[f] = out.f[f].reserved, densest[f] = densest_[f];
         consumed = consumed_;
     }
     // file f's writable mapping ends at `target` from now on -- unless a place beyond it was handed out already
@@ -723,6 +726,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     uint64_t next_ = 0, consumed_ = 0;
+    double densest_[NFILES] = {0, 0, 0, 0};
 };
 
 // The prepared tails are sized from an estimate on the generous side, and what is too much has to be given back: cutting
@@ -770,7 +774,8 @@ private:
             seen = pokes_;
             g.unlock();
             uint64_t used[NFILES], consumed = 0;
-            order_.snapshot(out_, used, consumed);
+            double densest[NFILES];
+            order_.snapshot(out_, used, consumed, densest);
             const double share = std::min(1.0, (double)consumed / (double)input_bytes_);
             // (the files side by side: every inode has its own lock, and MS mode has two large ones to cut)
             std::vector<std::thread> cuts;
@@ -784,10 +789,15 @@ private:
                 const int want_stage = share >= 0.7 ? 2 : (share >= 0.16 ? 1 : 0);
                 if (want_stage <= stage[f]) continue;
                 stage[f] = want_stage;
-                // the predicted final size + 5 % (1.5 % the second time) + 8 MB, on a page boundary
+                // the predicted final size + a margin + 8 MB, on a page boundary.  The margin follows what the super-batches so far
+                // say about their spread: 1.5 % (0.8 % the second time) when every one asked for the same bytes per input byte,
+                // more by how far the densest lay above the mean, 10 % (5 %) at most -- what it leaves is cut after the run
                 const double predicted = (double)used[f] / share;
+                const double mean = consumed ? (double)used[f] / (double)consumed : 0.0;
+                const double spread = mean > 0 ? std::max(0.0, densest[f] / mean - 1.0) : 0.1;
+                const double margin = want_stage == 2 ? std::min(1.05, 1.008 + spread) : std::min(1.10, 1.015 + 1.5 * spread);
                 // (never into the part that is registered with the device: pinned_size)
-                const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * (want_stage == 2 ? 1.015 : 1.05)) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
+                const uint64_t target = std::max<uint64_t>(((uint64_t)(predicted * margin) + min_ / 4 + 4095) & ~4095ull, (of.pinned_size + 4095) & ~4095ull);
                 const uint64_t before = of.map_size.load();
                 if (target + min_ >= before) continue;  // (nothing worth a system call)
                 cuts.emplace_back([this, f, target, before, &sum_mu] {

@@ -161,12 +161,14 @@ if os.environ.get("E2E_MS", "1") != "0":
         print(f"== -M -c -n, {n_ms} reads, {tag}: {dt:.2f}s wall; loading the index {load_s:.3f}s, processing the reads {proc_s:.3f}s = "
               f"{n_ms / max(proc_s, 1e-9) / 1e6:.2f} M reads/s (lengths {sizes['.lengths']:.0f} MB, pointers {sizes['.pointers']:.0f} MB, report {sizes['.report']:.0f} MB)")
         for l in err.splitlines():
-            if "[timing]" in l:
+            if "[timing]" in l or "[calls]" in l or "[phases]" in l:
                 print("   ", l.strip())
         sys.stdout.flush()
 
     run_ms("SPUMONI_CACHE=write", {"SPUMONI_CACHE": "write"})
     run_ms("flat-layout cache", {})
+    if os.environ.get("E2E_MS_TRACE"):  # (when every worker was inside the library, and the device's own phase times)
+        run_ms("flat-layout cache, SPUMONI_CALL_TRACE + SPX_PHASE_TRACE", {"SPUMONI_CALL_TRACE": "1", "SPX_PHASE_TRACE": "1"})
     for e in (".lengths", ".pointers", ".report"):
         os.replace(f"{dm}/reads.fa{e}", f"{dm}/mapped{e}")
     run_ms("SPUMONI_MAP_OUTPUT=0 (plain writes, one writer thread per file)", {"SPUMONI_MAP_OUTPUT": "0"})
