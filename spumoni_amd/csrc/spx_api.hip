@@ -1640,7 +1640,7 @@ int spx_index_save(spx_index* ix, const char* path) {
     }
     h.device_bytes = ix->device_bytes;
     memcpy(h.source_tag, ix->source_tag, sizeof h.source_tag);
-    // the fat table and fat_j are not written: spx_index_load_flat rebuilds them from the other arrays (build_fat)
+    // the fat table and fat_js are not written: spx_index_load_flat rebuilds them from the other arrays (build_fat)
     uint64_t off = (sizeof h + 4095) & ~4095ull;
     for (int i = 0; i < spx_index::NARR; ++i) {
         const bool skip = i == A_FAT || i == A_FATJ;
@@ -1712,7 +1712,7 @@ spx_index* spx_index_load_flat(const char* path, int device) {
         want[A_ROWS] = (r + ROW_PAD) * row_bytes;
         want[A_DIRROWS] = (r + ROW_PAD) * sizeof(spx::JumpRow);
         want[A_FAT] = (h.view.nfat + 2) * (uint64_t)h.view.fat_stride;
-        want[A_FATJ] = h.view.nfat * 4 + 64;
+        want[A_FATJ] = spx::fatjs_count(h.view.nfat) * 4 + 64;
         want[A_Q] = (r + 1 + Q_PAD) * 4;
         want[A_AUX] = aux ? (r + 2) * sizeof(spx::Aux) : 0;
         want[A_SSRUN] = h.has_samples ? (r + 4) * 8 : 0;

@@ -241,79 +241,97 @@ __global__ void k_max_len(const uint64_t* lens, uint64_t r, unsigned long long* 
     if ((threadIdx.x & 63) == 0) atomicMax(out, v);
 }
 
-// block count table of letter c: cnt[fbase_c + b] = directory position of the first c-run whose
-// block (fat_block(run, bmul_c)) is >= b; qend_c when there is none.  blockIdx.y walks the letters that
-// occur, blockIdx.x strides over the letter's directory positions.
-// Round 5: a lane fills short gaps itself; a gap of more than 16 blocks -- on a real BWT the runs of a letter cluster, and
-// between the clusters lie hundreds of thousands of blocks without one -- is filled by the lane's whole wavefront, 64 blocks an
-// iteration (a lane alone used to walk them one store at a time: 0.16 s of the 0.6 s it takes `spumoni run` to load a 5-strain
-// E. coli index from the cache, against 1 ms for the stores themselves).
-__global__ void k_fill_cnt(const uint32_t* Qall, const LetterInfo* letters, const uint8_t* lets, uint64_t r,
-                           uint32_t* cnt) {
+// The fat table of letter c, one lane per directory position i of the letter (and one more for what lies behind its last
+// run): the slots of the blocks (block of the letter's previous run, block of run Q[i]] all hold the digest of the jump row
+// of run Q[i] -- the first run of the letter at or after their block -- and only the last of them can be FAT_SINGLE.
+// Samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride).  Every first slot of a group
+// of 8 also leaves its directory position in fat_js.  blockIdx.y walks the letters that occur (lets[]), blockIdx.x strides
+// over the letter's directory positions.
+// A lane fills short stretches itself; a stretch of more than 16 slots -- on a real BWT the runs of a letter cluster, and
+// between the clusters lie hundreds of thousands of blocks without one -- is filled by the lane's whole wavefront, 64 slots an
+// iteration (round 5 found a lane alone walking such gaps one store at a time: 0.16 s of the 0.6 s it takes `spumoni run`
+// to load a 5-strain E. coli index from the cache).
+// (Until round 6 a first kernel wrote every slot's directory position into fat_j -- 4 bytes a slot, kept for the walk -- and
+// a second one, a lane per SLOT, packed the digests from it.)
+struct SlotImage {
+    uint64_t w[4];  // FatRow, then the slot's second half (fat_stride 32)
+};
+__global__ void k_fill_fat(const JumpRow* dirrows, const Aux* aux, const uint32_t* Qall, const LetterInfo* letters,
+                           const uint8_t* lets, uint64_t r, char* fat, uint32_t stride, uint32_t* fat_js, int force_esc,
+                           const Row* rows, int compact) {
     const LetterInfo li = letters[lets[blockIdx.y]];
-    uint32_t* row = cnt + li.fbase;
-    const int64_t nblk = (int64_t)fat_block((uint32_t)r, li.bmul) + 2;
+    const int64_t nslots = (int64_t)letter_slots((uint32_t)r, li.bmul);
     const uint32_t lane = threadIdx.x & 63;
-    // [lo, hi] := val, by the lane itself when the gap is short, by the wavefront otherwise (every lane of the wavefront
+    auto put = [&](int64_t x, const SlotImage& v, uint32_t j) {
+        const uint64_t i = li.fbase + (uint64_t)x;
+        uint64_t* slot = reinterpret_cast<uint64_t*>(fat + i * stride);
+        slot[0] = v.w[0];
+        slot[1] = v.w[1];
+        if (stride == 32) {
+            slot[2] = v.w[2];
+            slot[3] = v.w[3];
+        }
+        if ((i & (FJ_GROUP - 1)) == 0) fat_js[i >> FJ_SHIFT] = j;
+    };
+    // [lo, hi] := v, by the lane itself when the stretch is short, by the wavefront otherwise (every lane of the wavefront
     // calls this in every round: the trip count below is the same for all of them)
-    auto fill = [&](bool have, int64_t lo, int64_t hi, uint32_t val) {
+    auto fill = [&](bool have, int64_t lo, int64_t hi, const SlotImage& v, uint32_t j) {
         const bool big = have && hi - lo >= 16;
         if (have && !big)
-            for (int64_t x = lo; x <= hi; ++x) row[x] = val;
+            for (int64_t x = lo; x <= hi; ++x) put(x, v, j);
         uint64_t todo = __builtin_amdgcn_ballot_w64(big);
         while (todo != 0) {
             const int l = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const int64_t glo = __shfl((long long)lo, l), ghi = __shfl((long long)hi, l);
-            const uint32_t gv = (uint32_t)__shfl((int)val, l);
-            for (int64_t x = glo + lane; x <= ghi; x += 64) row[x] = gv;
+            SlotImage gv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gv.w[t] = (uint64_t)__shfl((long long)v.w[t], l);
+            const uint32_t gj = (uint32_t)__shfl((int)j, l);
+            for (int64_t x = glo + lane; x <= ghi; x += 64) put(x, gv, gj);
         }
     };
-    const uint64_t n_i = (uint64_t)li.qend - li.qbeg, stride = (uint64_t)gridDim.x * TPB;
-    const uint64_t rounds = (n_i + stride - 1) / stride;
+    const uint64_t n_i = (uint64_t)li.qend - li.qbeg + 1, step = (uint64_t)gridDim.x * TPB;
+    const uint64_t rounds = (n_i + step - 1) / step;
     for (uint64_t it = 0; it < rounds; ++it) {
-        const uint64_t i = li.qbeg + blockIdx.x * (uint64_t)TPB + threadIdx.x + it * stride;
-        const bool live = i < li.qend;
-        int64_t b = 0, pb = -1;
-        if (live) {
-            b = fat_block(Qall[i], li.bmul);
-            pb = i > li.qbeg ? (int64_t)fat_block(Qall[i - 1], li.bmul) : -1;
-        }
-        fill(live, pb + 1, b, (uint32_t)i);
-        fill(live && i + 1 == li.qend, b + 1, nblk - 1, li.qend);  // behind the letter's last run
-    }
-}
-
-// fat slot = digest of the jump row of the first c-run at or after the slot's block;
-// samples / dirdocs of that directory position ride in the same slot (DevIndex::fat_stride).
-// blockIdx.y walks the letters that occur (lets[]), blockIdx.x strides over the letter's slots.
-__global__ void k_fill_fat(const uint32_t* cnt, const JumpRow* dirrows, const Aux* aux, const uint32_t* Qall,
-                           const LetterInfo* letters, const uint8_t* lets, uint64_t r, char* fat, uint32_t stride,
-                           int force_esc, const Row* rows, int compact) {
-    const LetterInfo li = letters[lets[blockIdx.y]];
-    const uint64_t nblk = (uint64_t)fat_block((uint32_t)r, li.bmul) + 2;
-    for (uint64_t b = blockIdx.x * (uint64_t)TPB + threadIdx.x; b < nblk; b += (uint64_t)gridDim.x * TPB) {
-        const uint64_t i = li.fbase + b;
-        const uint32_t j = cnt[i];
-        char* slot = fat + i * stride;
+        const uint64_t t = blockIdx.x * (uint64_t)TPB + threadIdx.x + it * step;
+        const bool live = t < n_i;
+        const uint32_t j = li.qbeg + (uint32_t)(live ? t : 0);
+        const bool tail = j >= li.qend;  // behind the letter's last run: no successor
+        int64_t b = nslots - 1, pb = -1;
         bool single = false;
-        if (j < li.qend && fat_block(Qall[j], li.bmul) == b)
-            single = (j + 1 >= li.qend) || fat_block(Qall[j + 1], li.bmul) > b;
-        // Hp: the head of the run a predecessor jump lands in when that is not the successor's landing run
-        const JumpRow jr = dirrows[j];
-        const uint32_t srun = jr_sLFrun(jr);
-        uint32_t Hp = 0;
-        if (!jr_psame(jr) && srun > 0 && srun <= r) {
-            const Row& pr = *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) +
-                                                           (uint64_t)(srun - 1) * (compact ? sizeof(Row32) : sizeof(Row)));
-            Hp = compact ? crow_H(pr) : row_H(pr);
+        SlotImage plain{{0, 0, 0, 0}}, last{{0, 0, 0, 0}};
+        if (live) {
+            if (!tail) {
+                b = fat_block(Qall[j], li.bmul);
+                single = (j + 1 >= li.qend) || fat_block(Qall[j + 1], li.bmul) > b;
+            }
+            pb = j > li.qbeg ? (int64_t)fat_block(Qall[j - 1], li.bmul) : -1;
+            // Hp: the head of the run a predecessor jump lands in when that is not the successor's landing run
+            const JumpRow jr = dirrows[j];
+            const uint32_t srun = jr_sLFrun(jr);
+            uint32_t Hp = 0;
+            if (!jr_psame(jr) && srun > 0 && srun <= r) {
+                const Row& pr = *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) +
+                                                               (uint64_t)(srun - 1) * (compact ? sizeof(Row32) : sizeof(Row)));
+                Hp = compact ? crow_H(pr) : row_H(pr);
+            }
+            const FatRow f0 = pack_fatrow(jr, tail, j <= li.qbeg, force_esc != 0, false, Hp, j);
+            const FatRow f1 = pack_fatrow(jr, tail, j <= li.qbeg, force_esc != 0, single, Hp, j);
+            plain.w[0] = f0.w0, plain.w[1] = f0.w1;
+            if (aux) {
+                const Aux a = aux[j];
+                plain.w[2] = a.a0, plain.w[3] = a.a1;
+            } else if (stride == 32 && srun <= r) {  // (PML-only, compact rows) the row of the landing run rides along: spx_walk_fast.inc, lrow
+                const Row lr = *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) + (uint64_t)srun * sizeof(Row32));
+                plain.w[2] = lr.q0, plain.w[3] = lr.q1;
+            }
+            last = plain;
+            last.w[0] = f1.w0, last.w[1] = f1.w1;
         }
-        *reinterpret_cast<FatRow*>(slot) = pack_fatrow(jr, j >= li.qend, j <= li.qbeg, force_esc != 0, single, Hp);
-        if (aux)
-            *reinterpret_cast<Aux*>(slot + sizeof(FatRow)) = aux[j];
-        else if (stride == 32)  // (PML-only, compact rows) the row of the landing run rides along: spx_walk_fast.inc, lrow
-            *reinterpret_cast<Row*>(slot + sizeof(FatRow)) =
-                srun <= r ? *reinterpret_cast<const Row*>(reinterpret_cast<const char*>(rows) + (uint64_t)srun * sizeof(Row32)) : Row{0, 0};
+        // the blocks before the run's own (or, behind the last run, all that are left), then the run's own block
+        fill(live, pb + 1, tail ? b : b - 1, plain, j);
+        if (live && !tail && pb < b) put(b, last, j);  // (pb == b: the block's slot belongs to an earlier run of the letter)
     }
 }
 
@@ -351,9 +369,9 @@ __global__ void k_samples(const uint64_t* ssa, const uint64_t* esa, const uint32
 
 }  // namespace
 
-// The fat table and fat_j from what the index already holds on the device: letters (geometry), Q, dirrows, aux.
+// The fat table and fat_js from what the index already holds on the device: letters (geometry), Q, dirrows, aux.
 // Run by the flatten step and by spx_index_load_flat: the cache file does not carry the table (it is most of the
-// index -- 150 of 204 GB at 10^9 runs -- and takes a fraction of a second to rebuild, seconds to read).
+// index -- 160 of 230 GB at 10^9 runs -- and takes a fraction of a second to rebuild, seconds to read).
 int build_fat(spx_index* ix) {
     hipStream_t st = nullptr;
     const uint64_t r = ix->view.r, nfat = ix->view.nfat;
@@ -361,12 +379,15 @@ int build_fat(spx_index* ix) {
     std::vector<LetterInfo> hl(256);
     SPX_HIP(hipMemcpy(hl.data(), ix->letters, 256 * sizeof(LetterInfo), hipMemcpyDeviceToHost));
     std::vector<uint8_t> lets;
-    uint64_t most_slots = 0, most_runs = 0;
+    uint64_t most_runs = 0;
     for (int c = 0; c < 256; ++c)
         if (hl[c].qend > hl[c].qbeg) {
             lets.push_back((uint8_t)c);
-            most_slots = std::max<uint64_t>(most_slots, (uint64_t)fat_block((uint32_t)r, hl[c].bmul) + 2);
             most_runs = std::max<uint64_t>(most_runs, hl[c].qend - hl[c].qbeg);
+            if ((hl[c].fbase & (FJ_GROUP - 1)) != 0 || hl[c].fbase + letter_slots((uint32_t)r, hl[c].bmul) > nfat) {
+                set_error("index letters describe a fat table that does not fit its %llu slots", (unsigned long long)nfat);
+                return SPX_E_FORMAT;
+            }
         }
     if (lets.empty()) {
         set_error("index without letters");
@@ -375,37 +396,30 @@ int build_fat(spx_index* ix) {
     DevBuf dl;
     SPX_HIP(dl.alloc(256));
     SPX_HIP(hipMemcpyAsync(dl.p, lets.data(), lets.size(), hipMemcpyHostToDevice, st));
-    if (ix->fat_j) (void)hipFree(ix->fat_j);
+    if (ix->fat_js) (void)hipFree(ix->fat_js);
     if (ix->fat) (void)hipFree(ix->fat);
-    ix->fat_j = nullptr;
+    ix->fat_js = nullptr;
     ix->fat = nullptr;
     const bool timing = getenv("SPX_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    SPX_ALLOC0(ix->fat_j, nfat * 4 + 64);
+    SPX_ALLOC0(ix->fat_js, fatjs_count(nfat) * 4 + 64);
     SPX_ALLOC0(ix->fat, (nfat + 2) * (uint64_t)fat_stride);
     if (timing) {
         SPX_HIP(hipStreamSynchronize(st));
-        fprintf(stderr, "[spx] build_fat: allocate + zero %.1f GB: %.3f s\n", (nfat * (fat_stride + 4.0)) / 1e9, now() - t0);
+        fprintf(stderr, "[spx] build_fat: allocate + zero %.1f GB: %.3f s\n", (nfat * (fat_stride + 4.0 / FJ_GROUP)) / 1e9, now() - t0);
         t0 = now();
     }
     const uint32_t* Qall = ix->q_alloc + 1;
-    const unsigned gc = most_runs / TPB + 1 < (1u << 20) ? (unsigned)(most_runs / TPB + 1) : (1u << 20);
-    k_fill_cnt<<<dim3(gc, (unsigned)lets.size()), TPB, 0, st>>>(Qall, ix->letters, dl.as<uint8_t>(), r, ix->fat_j);
-    if (timing) {
-        SPX_HIP(hipStreamSynchronize(st));
-        fprintf(stderr, "[spx] build_fat: k_fill_cnt %.3f s\n", now() - t0);
-        t0 = now();
-    }
-    const unsigned gx = most_slots / TPB + 1 < (1u << 20) ? (unsigned)(most_slots / TPB + 1) : (1u << 20);
-    k_fill_fat<<<dim3(gx, (unsigned)lets.size()), TPB, 0, st>>>(ix->fat_j, ix->dirrows, ix->aux, Qall, ix->letters,
-                                                                 dl.as<uint8_t>(), r, ix->fat, fat_stride,
-                                                                 getenv("SPX_FAT_ALL_ESC") ? 1 : 0, ix->rows, (int)ix->view.compact);
+    const unsigned gc = (most_runs + 1) / TPB + 1 < (1u << 20) ? (unsigned)((most_runs + 1) / TPB + 1) : (1u << 20);
+    k_fill_fat<<<dim3(gc, (unsigned)lets.size()), TPB, 0, st>>>(ix->dirrows, ix->aux, Qall, ix->letters, dl.as<uint8_t>(), r, ix->fat,
+                                                                 fat_stride, ix->fat_js, getenv("SPX_FAT_ALL_ESC") ? 1 : 0, ix->rows,
+                                                                 (int)ix->view.compact);
     SPX_HIP(hipGetLastError());
     SPX_HIP(hipStreamSynchronize(st));
     if (timing) fprintf(stderr, "[spx] build_fat: k_fill_fat %.3f s\n", now() - t0);
     ix->arr_bytes[A_FAT] = (nfat + 2) * (uint64_t)fat_stride;
-    ix->arr_bytes[A_FATJ] = nfat * 4 + 64;
+    ix->arr_bytes[A_FATJ] = fatjs_count(nfat) * 4 + 64;
     bind_view(ix);
     return SPX_OK;
 }
@@ -861,14 +875,17 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
 
     // Fat-table geometry = how much HBM is traded for speed.  A fat slot answers a jump outright
     // when no c-run lies between its block's start and the walk's run, so smaller blocks mean fewer
-    // fat_j / Q / dirrow gathers (measured on C3, same box, uniform blocks: 884 / 975 / 1 051 /
+    // fat_js / Q / dirrow gathers (measured on C3, same box, uniform blocks: 884 / 975 / 1 051 /
     // 1 076 M reads/s at 64 / 32 / 16 / 8 runs per block).  Every letter gets its own block size
     // B_c = K * (r_c / r)^-alpha runs (r_c = runs of the letter): a slot fails with probability
     // ~ B_c * r_c / r / 2, so for a given number of slots the failures over all letters are fewest
     // with alpha = 1/2 when every letter is asked for equally often and with alpha = 1 when letters
     // are asked for as often as they head runs; 0.7 sits between (SPX_FAT_ALPHA overrides).  K is the
     // smallest value -- the densest tables -- that keeps the whole flat index within the budget:
-    // 66 % of the device's memory (SPX_INDEX_BUDGET_GB overrides) and what is free right now.
+    // 75 % of the device's memory (SPX_INDEX_BUDGET_GB overrides) and what is free right now.  (66 % until round 6: a real
+    // BWT, whose letters' runs cluster, keeps gaining up to ~16 slots per run -- 36.1 / 37.5 / 38.8 / 39.9 G steps/s at 6.8 /
+    // 8.4 / 11 / 16 on the 2.9 * 10^7-run index of profiles/r06_fat_table.txt -- and what a query context needs beside
+    // the index is a few GB.)
     size_t mem_free = 0, mem_total = 0;
     SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
     const bool has_ms = d_ssa && d_esa;
@@ -878,20 +895,20 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     const bool want_lrow = getenv("SPX_FAT_LROW") != nullptr && atoi(getenv("SPX_FAT_LROW")) != 0;
     const bool lrow = want_lrow && compact && !(has_ms || docs);
     const uint32_t fat_stride = fat_row_bytes + ((has_ms || docs || lrow) ? (uint32_t)sizeof(Aux) : 0);
-    const double per_slot = fat_stride + 4 /* fat_j */;
+    const double per_slot = fat_stride + 4.0 / FJ_GROUP /* fat_js */;
     // per-run arrays: rows 16 / 32 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
     const double fixed = (double)r * ((double)row_bytes + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));
     // still to be allocated from the free memory besides the fat table: Q, aux, ss_by_run and the
     // sample pairs scratch
     const double to_come = (double)r * (4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 + 16 : 0)) + (64 << 20);
-    double budget = 0.66 * (double)mem_total;
+    double budget = 0.75 * (double)mem_total;
     if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     double fat_bytes = budget - fixed;
     const double fat_bytes_free = 0.92 * (double)mem_free - to_come;
     if (fat_bytes > fat_bytes_free) fat_bytes = fat_bytes_free;
     double max_slots = fat_bytes > 0 ? fat_bytes / per_slot : 0;
     // past ~16 slots per run nothing is left to gain (at 7.6 a slot fails to answer ~4 % of the jumps it is asked,
-    // at 16 under 2 %): a small index does not take 66 % of the device for its table
+    // at 16 under 2 %): a small index does not take 75 % of the device for its table
     if (max_slots > 16.0 * (double)r) max_slots = 16.0 * (double)r;
     if (const char* e = getenv("SPX_FAT_SLOTS_PER_RUN")) max_slots = atof(e) * (double)r;  // test / experiment knob
     double alpha = 0.7;
@@ -914,7 +931,7 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
                 li.bmul = bmul;
                 li.fbase = slots;
             }
-            slots += (uint64_t)fat_block((uint32_t)r, bmul) + 2;
+            slots += letter_slots((uint32_t)r, bmul);
         }
         return (double)slots;
     };
@@ -969,7 +986,7 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
         const int rc_fat = build_fat(ix);
         if (rc_fat != SPX_OK) return rc_fat;
     }
-    bytes += nfat * 4 + 64;
+    bytes += fatjs_count(nfat) * 4 + 64;
     if (docs) {
         SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
@@ -994,7 +1011,7 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     ix->arr_bytes[A_ROWS] = (r + ROW_PAD) * row_bytes;
     ix->arr_bytes[A_DIRROWS] = (r + ROW_PAD) * sizeof(JumpRow);
     ix->arr_bytes[A_FAT] = (nfat + 2) * (uint64_t)fat_stride;
-    ix->arr_bytes[A_FATJ] = nfat * 4 + 64;
+    ix->arr_bytes[A_FATJ] = fatjs_count(nfat) * 4 + 64;
     ix->arr_bytes[A_Q] = (r + 1 + Q_PAD) * 4;
     ix->arr_bytes[A_AUX] = ix->aux ? (r + 2) * sizeof(Aux) : 0;
     ix->arr_bytes[A_SSRUN] = ix->ss_by_run ? (r + 4) * 8 : 0;

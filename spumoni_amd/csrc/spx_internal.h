@@ -152,7 +152,7 @@ struct spx_index {
     uint32_t* q_alloc = nullptr;  // Q = q_alloc + 1
     spx::JumpRow* dirrows = nullptr;
     char* fat = nullptr;  // slots of DevIndex::fat_stride bytes
-    uint32_t* fat_j = nullptr;
+    uint32_t* fat_js = nullptr;  // fatjs_count(nfat) entries
     spx::Aux* aux = nullptr;
     uint64_t* ss_by_run = nullptr;
     uint32_t* rundocs = nullptr;
@@ -222,7 +222,7 @@ inline void index_arrays(spx_index* ix, void*** out) {
     out[A_ROWS] = (void**)&ix->rows;
     out[A_DIRROWS] = (void**)&ix->dirrows;
     out[A_FAT] = (void**)&ix->fat;
-    out[A_FATJ] = (void**)&ix->fat_j;
+    out[A_FATJ] = (void**)&ix->fat_js;
     out[A_Q] = (void**)&ix->q_alloc;
     out[A_AUX] = (void**)&ix->aux;
     out[A_SSRUN] = (void**)&ix->ss_by_run;
@@ -240,7 +240,7 @@ inline void bind_view(spx_index* ix) {
     v.aux = ix->aux;
     v.ss_by_run = ix->ss_by_run;
     v.rundocs = ix->rundocs;
-    v.fat_j = ix->fat_j;
+    v.fat_js = ix->fat_js;
     v.letters = ix->letters;
     v.text = ix->text;
     v.n_text = ix->n_text;
@@ -259,7 +259,7 @@ inline int chunk_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
     *out = sc.p;
     return SPX_OK;
 }
-// spx_flatten.hip: (re)builds fat / fat_j from letters, Q, dirrows and aux (view.r / nfat / fat_stride set)
+// spx_flatten.hip: (re)builds fat / fat_js from letters, Q, dirrows and aux (view.r / nfat / fat_stride set)
 int build_fat(spx_index* ix);
 // spx_walk.hip: MS text against the index: text[samples_start[k]] must be the head of run k
 int launch_text_check(spx_index* ix, unsigned long long* d_bad, hipStream_t stream);

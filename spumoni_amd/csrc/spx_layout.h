@@ -26,8 +26,8 @@
 //      dirrows[j]            one JumpRow per run, in (letter, run index) order
 //      fat[fbase_c + blk_c(k)]  a 16-byte digest (FatRow) of the JumpRow of the first c-run at
 //                            or after block blk_c(k) = umulhi(k, bmul_c) of letter c: one 16-byte
-//                            gather answers most jumps outright; fat_j[..] is that run's
-//                            directory position.  Every letter has its own block size
+//                            gather answers most jumps outright; fat_js[slot >> FJ_SHIFT] is the
+//                            directory position the slot's group of 8 starts at.  Every letter has its own block size
 //                            2^32 / bmul_c (any real number >= 1), chosen at flatten time from the
 //                            letter's share of the runs: dense tables for the letters whose runs
 //                            are dense, coarse ones for the tail.
@@ -45,7 +45,7 @@
 // Names the flat layout AND the walk kernels that read it: a .spx cache written by another layout is
 // refused, and measured HBM traffic (profiles/traffic.json) is only quoted for the version it was
 // taken with.  Bump on any change to a record in this file or to the walk's access pattern.
-#define SPX_LAYOUT_VERSION "spx-flat-r04a"
+#define SPX_LAYOUT_VERSION "spx-flat-r06a"
 
 namespace spx {
 
@@ -174,9 +174,13 @@ SPX_HD uint32_t jr_j(const JumpRow& d) { return (uint32_t)d.d3; }
 // the threshold run as a 20-bit distance below q, the two offsets in 16 bits, no j.  Where the predecessor landing is
 // the last position of run sLFrun - 1 (psame = 0, which means sLFoff = 0) the sLFoff field holds Hp, the head of THAT
 // run: a predecessor jump followed by another jump then needs no landing gather either (5 % of the C3 walk's gathers).
-// `esc` marks a slot whose row does not fit; the walk then fetches the slot's directory position
-// from fat_j and reads the full JumpRow (it does the same when the slot's run lies before the
-// walk's run and the directory has to be scanned).
+// `esc` marks a slot whose row does not fit; it holds its run's directory position instead (w0: q | j << 32; of w1 only
+// the flag bits and FAT_SINGLE) and the walk reads the full JumpRow there.  When the slot's run lies before the walk's run
+// (and the next slot is not the answer, FAT_SINGLE) the directory is scanned: from fat_js[slot >> FJ_SHIFT], the directory
+// position of the first run of the letter at or after the block of the first slot of the slot's group of 8.  (Round 6: until
+// then every slot had its directory position beside it, 4 of 20 bytes a slot -- a fifth of the table for a path 2-3 % of
+// the jumps take; the same memory now holds 8.2 instead of 6.8 slots per run, and on a real BWT, where a letter's runs
+// cluster, that is what the walk is short of: tools/fat_geom_sim.py, profiles/r06_fat_table.txt.)
 // nosucc: the slot points past the letter's last run (no c-run at or after the block);
 // first: the slot's run is the letter's first run (a predecessor jump from it is undefined).
 struct alignas(16) FatRow {
@@ -187,9 +191,12 @@ struct alignas(16) FatRow {
 // single: the slot's run lies in the slot's own block and the letter's NEXT run lies in a later
 // block.  A walk that finds the slot's run before its own run (the slot cannot answer) then knows
 // that the successor is the run of the NEXT slot -- one more 16-byte load, next to the first one,
-// instead of fat_j -> Q -> dirrows.
+// instead of fat_js -> Q -> dirrows.
 constexpr uint64_t FAT_SINGLE = 1ull << 19;
-SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_esc, bool single, uint32_t Hp) {
+constexpr int FJ_SHIFT = 3;  // one directory position per 2^FJ_SHIFT slots; every letter's first slot is a multiple of that
+constexpr uint64_t FJ_GROUP = 1ull << FJ_SHIFT;
+SPX_HD uint64_t fatjs_count(uint64_t nfat) { return (nfat >> FJ_SHIFT) + 2; }
+SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_esc, bool single, uint32_t Hp, uint32_t j) {
     const uint32_t q = (uint32_t)f.d0, trun = (uint32_t)(f.d0 >> 32);
     const uint64_t toff = f.d1 & MASK40, soff = f.d2 & MASK40;
     const uint32_t srun = (uint32_t)(f.d1 >> 40) | ((uint32_t)((f.d2 >> 40) & 0xff) << 24);
@@ -197,6 +204,11 @@ SPX_HD FatRow pack_fatrow(const JumpRow& f, bool nosucc, bool first, bool force_
     const bool esc = force_esc || soff >= (1u << 16) ||
                      (!nosucc && (trun > q || dthr >= (1u << 19) || toff >= (1u << 16)));
     FatRow h;
+    if (esc) {  // the row does not fit: the slot names its directory position
+        h.w0 = (uint64_t)q | ((uint64_t)j << 32);
+        h.w1 = (single ? FAT_SINGLE : 0) | ((uint64_t)(nosucc ? 1 : 0) << 61) | (1ull << 62) | ((uint64_t)(first ? 1 : 0) << 63);
+        return h;
+    }
     h.w0 = (uint64_t)q | ((uint64_t)srun << 32);
     const bool psame = (f.d2 >> 48) & 1;  // (= soff > 0)
     h.w1 = (dthr & 0x7ffff) | (single ? FAT_SINGLE : 0) | ((toff & 0xffff) << 20) | (((psame ? soff : (uint64_t)(Hp & 0xff)) & 0xffff) << 36) |
@@ -216,6 +228,9 @@ struct alignas(16) LetterInfo {
     uint64_t fbase;  // first fat slot of the letter
 };
 SPX_HD uint32_t fat_block(uint32_t k, uint32_t bmul) { return (uint32_t)(((uint64_t)k * bmul) >> 32); }
+// slots of a letter: a block for every run index up to r (the sentinel position), one more for the next-slot shortcut
+// (FAT_SINGLE), rounded up to whole groups of 8 (FJ_SHIFT below); all slots past the letter's last run say `nosucc`
+SPX_HD uint64_t letter_slots(uint32_t r, uint32_t bmul) { return ((uint64_t)fat_block(r, bmul) + 2 + 7) & ~7ull; }
 
 // Side data of directory position j, everything a jump to run Q[j] (or to the end of run Q[j-1])
 // hands out in MS / doc mode, in 16 bytes:
@@ -252,7 +267,7 @@ struct DevIndex {
     // a fat slot is fat_stride bytes: the FatRow, then (index with SA samples or documents) the Aux
     // of that directory position at +16 -- everything a jump needs in MS / doc mode sits in the
     // same 32 aligned bytes
-    const uint32_t* fat_j; // directory position of every slot's run
+    const uint32_t* fat_js; // per group of 8 slots: directory position of the first run of the letter at or after the group's first block
     uint32_t fat_stride;   // 16 or 32
     const LetterInfo* letters;  // 256 entries
     const uint8_t* text;        // MS extension text or nullptr
@@ -261,7 +276,7 @@ struct DevIndex {
     uint32_t r;         // runs of the flat layout (pieces of long runs count: >= the file's r, spx_index::r)
     uint32_t compact;   // rows use the compact encoding (every run / piece shorter than 2^16)
     uint32_t nletters;  // byte values that occur in the BWT
-    uint64_t nfat;      // fat slots in all (every letter: fat_block(r, bmul) + 2)
+    uint64_t nfat;      // fat slots in all (every letter: fat_block(r, bmul) + 2, rounded up to a whole group of 8)
     uint32_t init_k;    // run of position n-1  (= r-1)
     uint64_t init_off;  // (n-1) - S[r-1]
     Row32 init_row;     // rows[r-1]: every read starts on it, so the walk never gathers it (general rows: q0, q1)

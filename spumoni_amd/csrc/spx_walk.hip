@@ -20,10 +20,10 @@
 //   P_FAT    fat[fbase_c + blk_c(k)]      16 B  (digest of the jump row of the first c-run
 //                                                at or after the block: usually THE answer;
 //                                                the next slot when this one says so)
-//   P_FATJ   fat_j[fbase_c + blk_c(k)]     4 B  (only if the digest does not hold the row, or
-//                                                the block holds c-runs < k: where to go on)
-//   P_QS     Q[j .. j+8)                  32 B  (only if the block holds c-runs < k)
-//   P_DIR    dirrows[j]                   32 B  (only after P_FATJ / P_QS)
+//   P_FATJ   fat_js[slot >> 3]             4 B  (only if the block holds c-runs < k -- or a byte >= 128 sits on its
+//                                                own run with a threshold to be asked: where the scan starts)
+//   P_QS     Q[j .. j+8)                  32 B  (after P_FATJ: the first run of the letter at or after k)
+//   P_DIR    dirrows[j]                   32 B  (after P_QS, or when the digest does not hold the row: it holds j)
 //   P_AUX / P_SAMP                              (MS samples / document ids)
 //
 // then consumes it and moves to the next phase.  Because the load site is
@@ -219,8 +219,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
     const char* const rows_b = reinterpret_cast<const char*>(ix.rows);
     const char* const dir_b = reinterpret_cast<const char*>(ix.dirrows);
     const char* const fat_b = reinterpret_cast<const char*>(ix.fat);
-    const char* const fatj_b = reinterpret_cast<const char*>(ix.fat_j);
-    bool fat_found = false;  // P_FAT -> P_FATJ: the slot's run IS the successor (its row did not fit 16 bytes)
+    const char* const fatj_b = reinterpret_cast<const char*>(ix.fat_js);
     uint32_t fadd = 0;       // 1: the jump is looking at the slot AFTER its block's (FAT_SINGLE)
     constexpr uint32_t FAT_ROW = sizeof(FatRow);
     const char* const q_b = reinterpret_cast<const char*>(ix.Q);
@@ -327,8 +326,8 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
             p0 = fat_b + fidx * ix.fat_stride;
         } else if (ph == P_FATJ) {
-            fidx = s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd;
-            p0 = fatj_b + ((fidx * 4) & ~15ull);  // the aligned 16 bytes that hold fat_j[fidx]
+            fidx = (s_let[c].fbase + fat_block(k, s_let[c].bmul) + fadd) >> FJ_SHIFT;  // the slot's group
+            p0 = fatj_b + ((fidx * 4) & ~15ull);  // the aligned 16 bytes that hold fat_js[group]
         } else if (ph == P_DIR) {
             p0 = dir_b + (uint64_t)jdir * sizeof(JumpRow);
         } else if (ph == P_QS) {
@@ -396,7 +395,7 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
             const bool nosucc = (g1 >> 61) & 1, esc = (g1 >> 62) & 1;
             // the block's first c-run is the successor unless it lies before k (or is k
             // itself when the walk sits on a c-run: byte >= 128, Appendix C1)
-            fat_found = nosucc || hq > k || (quirk && hq == k);
+            const bool fat_found = nosucc || hq > k || (quirk && hq == k);
             if (fat_found && !esc && !quirk) {
                 // the 16 bytes are the whole answer: spread them into JumpRow form for the decision
                 // below (j is not known and not needed: only its place in [qbeg, qend] matters)
@@ -411,21 +410,18 @@ __global__ void __launch_bounds__(WALK_TPB) k_walk_lanes(const DevIndex ix, cons
                 do_decide = true;
             } else if (!fat_found && (g1 & FAT_SINGLE) && fadd == 0) {
                 fadd = 1;  // the letter's next run lies past this block: it is the next slot's run
+            } else if (fat_found && esc && !quirk) {
+                jdir = (uint32_t)(g0 >> 32);  // the row did not fit the digest: the slot names its directory position
+                ph = P_DIR;
             } else {
-                ph = P_FATJ;  // need the slot's directory position: full row, or a scan from there
+                ph = P_FATJ;  // scan the directory for the first run of the letter at or after k
             }
         } else if (ph == P_FATJ) {
             n_dir++;
             const uint32_t sel = (uint32_t)fidx & 3;
             const uint64_t gsel = (sel & 2) ? g1 : g0;
-            const uint32_t ej = (sel & 1) ? (uint32_t)(gsel >> 32) : (uint32_t)gsel;
-            if (fat_found) {
-                jdir = ej;
-                ph = P_DIR;
-            } else {
-                jdir = ej + 1;  // scan the directory from the next c-run on
-                ph = P_QS;
-            }
+            jdir = (sel & 1) ? (uint32_t)(gsel >> 32) : (uint32_t)gsel;  // where the slot's group starts in the directory
+            ph = P_QS;
         } else if (ph == P_QS) {
             n_dir++;
             const uint32_t e[8] = {(uint32_t)g0, (uint32_t)(g0 >> 32), (uint32_t)g1, (uint32_t)(g1 >> 32),
