@@ -1362,7 +1362,7 @@ extern "C" void park_on_sigbus(int) {
 void settle_outputs(bool run_is_over) {
     std::lock_guard<std::mutex> g(g_settle_mu);
     if (!g_live_outputs) return;
-    {
+    if (!run_is_over) {  // (the fatal way out only: at the ordinary end every writer has been joined and a SIGBUS is a real one)
         struct sigaction sa;
         std::memset(&sa, 0, sizeof sa);
         sa.sa_handler = park_on_sigbus;
@@ -1407,8 +1407,12 @@ static void prepare_one(OutputFiles* out, int f, const std::string& final_path, 
     const auto tick = [] { return std::chrono::steady_clock::now(); };
     const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     OutFile& of = out->f[f];
+    remove_stale_leftovers(final_path);  // (what a killed run of the same pattern file left behind)
     of.temp_path = final_path + ".partial." + std::to_string((long)::getpid());
-    const int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    // (a name nobody else can have made: O_EXCL, and no symbolic link planted in a shared directory is followed)
+    int fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0644);
+    if (fd < 0 && errno == EEXIST && ::unlink(of.temp_path.c_str()) == 0)  // (our own pid's name from an earlier life)
+        fd = ::open(of.temp_path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0644);
     if (fd < 0) return;
     register_leftover(of.temp_path);
     const uint64_t size = (est + 4095) & ~4095ull;

@@ -1,10 +1,14 @@
 #include "reads.hpp"
 
+#include <dirent.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <cerrno>
 #include <mutex>
 
 #include <algorithm>
@@ -26,26 +30,76 @@ namespace spumoni_host {
 // buffered (the output files are written with pwrite and need nothing) and leave without them.
 // outputs of an earlier run that were moved aside to be removed in the background (classify.cpp, OutFile::open): whoever
 // ends the process first makes sure none of them stays behind
+// (round 6: a fixed table of C strings, so that a signal handler can walk it too -- SIGINT / SIGTERM / SIGHUP used to leave
+// the prepared multi-GB files behind, on tmpfs that is RAM: ADVICE r5)
 static std::mutex g_leftover_mu;
-static std::vector<std::string> g_leftovers;
+static constexpr int MAX_LEFTOVERS = 64;
+static char* g_leftovers[MAX_LEFTOVERS];
+static std::atomic<int> g_nleftovers{0};
+extern "C" void remove_leftovers_on_signal(int sig) {
+    const int n = g_nleftovers.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (g_leftovers[i]) (void)::unlink(g_leftovers[i]);  // (async-signal-safe)
+    ::_exit(128 + sig);
+}
 void register_leftover(const std::string& path) {
     std::lock_guard<std::mutex> g(g_leftover_mu);
-    g_leftovers.push_back(path);
+    const int n = g_nleftovers.load(std::memory_order_relaxed);
+    if (n >= MAX_LEFTOVERS) return;
+    g_leftovers[n] = ::strdup(path.c_str());
+    g_nleftovers.store(n + 1, std::memory_order_release);
+    static bool handlers = false;
+    if (!handlers) {  // the first file that must not stay behind: from now on an interrupted run takes them along
+        handlers = true;
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = remove_leftovers_on_signal;
+        sigemptyset(&sa.sa_mask);
+        for (int sig : {SIGINT, SIGTERM, SIGHUP}) {
+            struct sigaction old;
+            if (::sigaction(sig, nullptr, &old) == 0 && old.sa_handler == SIG_DFL) (void)::sigaction(sig, &sa, nullptr);
+        }
+    }
 }
 void remove_leftovers() {
     std::lock_guard<std::mutex> g(g_leftover_mu);
-    for (const auto& p : g_leftovers) (void)::unlink(p.c_str());  // (already gone: fine)
-    g_leftovers.clear();
+    const int n = g_nleftovers.load(std::memory_order_relaxed);
+    for (int i = 0; i < n; ++i)
+        if (g_leftovers[i]) (void)::unlink(g_leftovers[i]);  // (already gone: fine)
+}
+
+// `<final>.partial.<pid>` / `<final>.old.<pid>` of a run that was killed outright (SIGKILL, out of memory): nothing of it could
+// clean up.  The next run over the same pattern file does, for every such name whose process is gone.
+void remove_stale_leftovers(const std::string& final_path) {
+    const size_t slash = final_path.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : final_path.substr(0, slash);
+    const std::string base = slash == std::string::npos ? final_path : final_path.substr(slash + 1);
+    DIR* d = ::opendir(dir.c_str());
+    if (!d) return;
+    while (struct dirent* e = ::readdir(d)) {
+        const std::string name = e->d_name;
+        for (const char* mark : {".partial.", ".old."}) {
+            const std::string pre = base + mark;
+            if (name.size() <= pre.size() || name.compare(0, pre.size(), pre) != 0) continue;
+            char* endp = nullptr;
+            const long pid = std::strtol(name.c_str() + pre.size(), &endp, 10);
+            if (pid <= 0 || *endp != 0 || pid == (long)::getpid()) continue;
+            if (::kill((pid_t)pid, 0) != 0 && errno == ESRCH) (void)::unlink((dir + "/" + name).c_str());
+        }
+    }
+    ::closedir(d);
 }
 
 static void (*g_exit_hook)() = nullptr;
 void set_exit_hook(void (*hook)()) { g_exit_hook = hook; }
 
 [[noreturn]] static void leave(int code) {
-    if (g_exit_hook) g_exit_hook();
-    remove_leftovers();
+    // (the hook cuts the output files under the device's and the pool's feet -- classify.cpp, settle_outputs -- so it comes
+    // last and nothing but _Exit follows it: ADVICE r5)
     std::cout.flush();
     std::fflush(nullptr);
+    remove_leftovers();
+    if (g_exit_hook) g_exit_hook();
     std::_Exit(code);
 }
 

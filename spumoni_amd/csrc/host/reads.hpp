@@ -103,6 +103,7 @@ private:
 // error helpers with the reference's message shapes (include/spumoni_main.hpp:28-33)
 void register_leftover(const std::string& path);  // a file to be gone when the process ends, however it ends
 void remove_leftovers();
+void remove_stale_leftovers(const std::string& final_path);  // <final>.partial.<pid> / .old.<pid> of processes that are gone
 void set_exit_hook(void (*hook)());               // called once on every way out through fatal_error / fatal_warning
 [[noreturn]] void fatal_error(const char* fmt, ...);
 [[noreturn]] void fatal_warning(const char* fmt, ...);

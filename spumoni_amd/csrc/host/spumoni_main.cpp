@@ -182,6 +182,16 @@ static void validate(const CliOptions& o) {  // include/spumoni_main.hpp:267-329
         fatal_warning("the bin size used is not optimal. Re-run using a value between 50 and 400.");
 }
 
+static std::vector<int> all_devices_twice() {
+    std::vector<int> v;
+    const int nd = std::max(1, spx_device_count());
+    for (int d = 0; d < nd; ++d) {
+        v.push_back(d);
+        v.push_back(d);
+    }
+    return v;
+}
+
 static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_main (:1305-1382)
     const char* tag = o.ms ? "compute_ms" : "compute_pml";
     IndexSet set;
@@ -211,12 +221,20 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
                 reads_err = e.what();
             }
         });
+    size_t auto_devices = 0;
+    if (o.devices.empty()) {  // no SPUMONI_GPUS: one device -> three workers on it, several -> all of them, two workers each
+        o.devices = spx_device_count() > 1 ? all_devices_twice() : std::vector<int>{0, 0, 0};
+        auto_devices = o.devices.size() / 2;
+    }
     std::thread pinned_loader;
     if (!o.is_general_text) pinned_loader = std::thread([&] { prepare_pinned_pool(o, std::max<size_t>(o.devices.size(), 1)); });
     set.load(o);
     if (reads_loader.joinable()) reads_loader.join();
     if (outputs_loader.joinable()) outputs_loader.join();
     if (pinned_loader.joinable()) pinned_loader.join();
+    // (the cores are shared out per distinct device: run_main sized them for one; the reads' loader is done with the count)
+    if (auto_devices > 1 && o.threads <= 1)
+        o.format_threads = std::max(1u, std::min(16u * (unsigned)auto_devices, std::thread::hardware_concurrency()));
     if (!reads_err.empty()) fatal_error("%s", reads_err.c_str());
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     std::cout << std::endl;
@@ -271,17 +289,15 @@ static int run_main(int argc, char** argv) {
     o.ms = (o.result_type == 0);
     // SPUMONI_GPUS: the device of every WORKER (a host thread that feeds a device from the one queue of parsed
     // super-batches).  Two entries that name the same device are two query contexts over one copy of the index: one's
-    // copies over PCIe run under the other's kernels.  Default: "0,0,0" (three keep the copy engines busy: files complete after
-    // 0.062-0.072 s against 0.076-0.081 with two, profiles/r05_cli_overlap.txt); "all": every visible device, twice.
-    o.devices = {0, 0, 0};
+    // copies over PCIe run under the other's kernels.  Default (resolved in run_spumoni, beside the threads that prepare the
+    // files: counting the devices starts the HIP runtime): one visible device -> "0,0,0" (three keep the copy engines busy:
+    // files complete after 0.062-0.072 s against 0.076-0.081 with two, profiles/r05_cli_overlap.txt); several -> every visible
+    // device, twice (the index replicated, the reads dealt to the workers: SURVEY 8(e)); "all" asks for the latter by name.
+    o.devices.clear();
     if (const char* g = std::getenv("SPUMONI_GPUS")) {
         o.devices.clear();
         if (std::strcmp(g, "all") == 0) {
-            const int nd = std::max(1, spx_device_count());
-            for (int d = 0; d < nd; ++d) {
-                o.devices.push_back(d);
-                o.devices.push_back(d);
-            }
+            o.devices = all_devices_twice();
         } else {
             std::stringstream ss(g);
             std::string tok;

@@ -679,6 +679,30 @@ static int ensure_scratch(spx_index* ix, int slot, size_t bytes, void** out) {
     return SPX_OK;
 }
 
+// The host-buffer entry points enqueue their copies on the handle's stream and leave early on any error after that.  A copy
+// that is still reading the caller's seqs / offsets / gap (or writing its outputs) when the call has already failed would
+// leave work in flight on memory the caller may free: every way out that is not SPX_OK waits for the stream first
+// (before the copies became asynchronous a failed call never left anything behind).
+namespace {
+struct QuietOnError {
+    hipStream_t st;
+    bool device_wide;  // the pipelined batches run on three streams of the handle: wait for the device
+    bool ok = false;
+    explicit QuietOnError(hipStream_t s, bool wide = false) : st(s), device_wide(wide) {}
+    int done(int rc) {
+        ok = rc == SPX_OK;
+        return rc;
+    }
+    ~QuietOnError() {
+        if (ok) return;
+        if (device_wide)
+            (void)hipDeviceSynchronize();
+        else
+            (void)hipStreamSynchronize(st);
+    }
+};
+}  // namespace
+
 int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint8_t* seqs, const uint64_t* offsets,
                      uint64_t nreads, uint8_t* out_seqs, uint64_t out_capacity, uint64_t* out_offsets) {
     if (!ix || !seqs || !offsets || !out_offsets) {
@@ -697,6 +721,7 @@ int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
     hipStream_t st = nullptr;
     if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    QuietOnError quiet(st);
     SPX_HIP(hipMemcpyAsync(dseq, seqs, total, hipMemcpyHostToDevice, st));
     SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     rc = spx_digest_batch_device(ix, kind, k, w, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total,
@@ -714,7 +739,7 @@ int spx_digest_batch(spx_index* ix, int kind, uint32_t k, uint32_t w, const uint
         SPX_HIP(hipMemcpyAsync(out_seqs, dout, dtotal, hipMemcpyDeviceToHost, st));
         SPX_HIP(hipStreamSynchronize(st));
     }
-    return SPX_OK;
+    return quiet.done(SPX_OK);
 }
 
 static int check_query(spx_index* ix, int mode, const void* seqs, const void* offs,
@@ -1074,16 +1099,19 @@ static int query_host_impl(spx_index* ix, int mode, const uint8_t* seqs, const u
     const uint64_t padded = ((total + 3) / 4) * 4 + 32;
     if ((rc = ensure_scratch(ix, 0, padded, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
-    if (pipelined)
-        return run_pipelined(ix, mode, seqs, offsets, nreads, (uint8_t*)dseq, (uint64_t*)doff, padded, out_lengths,
-                             out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
+    if (pipelined) {
+        QuietOnError quiet(nullptr, true);
+        return quiet.done(run_pipelined(ix, mode, seqs, offsets, nreads, (uint8_t*)dseq, (uint64_t*)doff, padded, out_lengths,
+                                        out_pointers, out_docs, out_class, bin_width, max_value_thr, width));
+    }
     hipStream_t st = nullptr;
     if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    QuietOnError quiet(st);
     SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     SPX_HIP(hipMemsetAsync((char*)dseq + total, 0, padded - total, st));
     SPX_HIP(hipMemcpyAsync(dseq, seqs, total, hipMemcpyHostToDevice, st));
-    return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
-                         out_pointers, out_docs, out_class, bin_width, max_value_thr, width);
+    return quiet.done(run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)doff, nreads, total, out_lengths,
+                                    out_pointers, out_docs, out_class, bin_width, max_value_thr, width));
 }
 
 int spx_query_batch(spx_index* ix, int mode, const uint8_t* seqs, const uint64_t* offsets,
@@ -1123,6 +1151,7 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
     if ((rc = ensure_scratch(ix, 7, (nreads + 1) * 8, &dooff)) != SPX_OK) return rc;
     hipStream_t st = nullptr;
     if ((rc = ctx_stream_of(ix, &st)) != SPX_OK) return rc;
+    QuietOnError quiet(st);
     SPX_HIP(hipMemcpyAsync(draw, seqs, total, hipMemcpyHostToDevice, st));
     SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
     const uint64_t* in_starts = nullptr;
@@ -1138,8 +1167,8 @@ int spx_digest_query_batch(spx_index* ix, int mode, int kind, uint32_t k, uint32
         return SPX_E_ARG;
     }
     // the digested reads never leave the device: the walk starts from the scratch buffers
-    return run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)dooff, nreads, dtotal, out_lengths,
-                         out_pointers, out_docs, out_class, bin_width, max_value_thr, 4, in_starts);
+    return quiet.done(run_and_fetch(ix, mode, (const uint8_t*)dseq, (const uint64_t*)dooff, nreads, dtotal, out_lengths,
+                                    out_pointers, out_docs, out_class, bin_width, max_value_thr, 4, in_starts));
 }
 
 // The same with everything resident in HBM and asynchronous on `stream`: DNA reads in, results at the digested reads'
@@ -1244,6 +1273,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     if ((rc = ensure_scratch(ix, digest_kind ? 6 : 0, padded, &dseq)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 1, (nreads + 1) * 8, &doff)) != SPX_OK) return rc;
     if ((rc = ensure_scratch(ix, 8, (nreads + 1) * 4, &dgap)) != SPX_OK) return rc;
+    QuietOnError quiet(st);  // (a failed call leaves nothing reading seqs / offsets / gap)
     SPX_HIP(hipMemcpyAsync(dseq, seqs, total_in, hipMemcpyHostToDevice, st));
     SPX_HIP(hipMemsetAsync((char*)dseq + total_in, 0, padded - total_in, st));
     SPX_HIP(hipMemcpyAsync(doff, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1342,7 +1372,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     }
     ix->text_nreads = nreads;
     ix->text_ready = true;
-    return SPX_OK;
+    return quiet.done(SPX_OK);
 }
 
 int spx_query_text_fetch(spx_index* ix, char* text[3], uint64_t* line_start[3]) {

@@ -60,6 +60,9 @@ struct spx_index {
     uint64_t tb[3];
     uint64_t tn;
     int ready;
+    /* the class records travel with the text: the caller's buffer is POISONED at begin and filled at fetch, as the real
+       library does (spx_query_text_fetch) -- a harness that reads them in between, or frees them, shows up on the CPU tier */
+    spx_class *cls_stash, *cls_out;
 };
 
 static spx_index *new_handle(core *c, int device) {
@@ -139,6 +142,7 @@ void spx_index_free(spx_index *ix) {
         free(c);
     }
     free_text_state(ix);
+    free(ix->cls_stash);
     free(ix);
 }
 
@@ -520,7 +524,12 @@ int spx_query_text_begin(spx_index *ix, int mode, int digest_kind, uint32_t k, u
     }
     vals v;
     const int want_len = (streams & SPX_TEXT_LENGTHS) != 0, want_doc = (streams & SPX_TEXT_DOCS) != 0;
-    int rc = run_query(ix, mode, qs, qo, nreads, want_len, want_doc, out_class, bin_width, max_value_thr, &v);
+    free(ix->cls_stash);
+    ix->cls_stash = out_class && nreads ? (spx_class *)malloc(nreads * sizeof(spx_class)) : NULL;
+    ix->cls_out = out_class;
+    int rc = run_query(ix, mode, qs, qo, nreads, want_len, want_doc, out_class ? (ix->cls_stash ? ix->cls_stash : out_class) : NULL,
+                       bin_width, max_value_thr, &v);
+    if (out_class && nreads) memset(out_class, 0xA5, nreads * sizeof(spx_class)); /* not yours before the fetch */
     if (rc == SPX_OK) {
         for (int i = 0; i < 3; ++i) {
             out_bytes[i] = 0;
@@ -583,6 +592,10 @@ int spx_query_text_fetch(spx_index *ix, char *text[3], uint64_t *line_start[3]) 
         if (text[i]) memcpy(text[i], ix->tx[i], ix->tb[i]);
         if (line_start && line_start[i]) memcpy(line_start[i], ix->ls[i], (ix->tn + 1) * 8);
     }
+    if (ix->cls_out && ix->cls_stash) memcpy(ix->cls_out, ix->cls_stash, ix->tn * sizeof(spx_class));
+    free(ix->cls_stash);
+    ix->cls_stash = NULL;
+    ix->cls_out = NULL;
     free_text_state(ix);
     return SPX_OK;
 }

@@ -190,14 +190,17 @@ def test_config1_ecoli_scale(gpu, oracle_mod):
     g = synth.random_genome(4_641_652, seed=1)
     text, doc_lengths = synth.pangenome_text([g])
     raw = synth.index_from_text(torch.from_numpy(text).cuda(), doc_lengths=doc_lengths, with_samples=False)
-    seqs, offs = synth.sample_reads(text, 20_000, 150, seed=11)
+    seqs, offs = synth.sample_reads(text, 100_000, 150, seed=11)  # the declared 100 000 x 150 bp
     ix = capi.Index.from_raw(raw, 0)
     got = ix.query_host(capi.SPX_MODE_PML, seqs, offs, classify=(150, 3 + 4))
     orc = oracle_mod.OracleIndex.from_raw(raw.cpu())
     want = orc.pml(seqs, offs)
     assert np.array_equal(got["lengths"], want)
+    # the .report's columns (compute_ms_pml.cpp:969-995): bins above / below the threshold, the sum their mean is printed from
     f, a, b, s = oracle_mod.classify(want, offs, 150, 7)
-    assert np.array_equal(got["class"]["above"], a)
+    assert np.array_equal(got["class"]["above"], a) and np.array_equal(got["class"]["below"], b)
+    assert np.array_equal(got["class"]["sum_max"], s)
+    assert np.array_equal(2 * got["class"]["above"].astype(np.int64) > got["class"]["above"].astype(np.int64) + got["class"]["below"], f.astype(bool))
     # sampled reads are FOUND, reversed (null) reads are not: the classifier separates them
     assert 0.3 < f.mean() < 0.7
 

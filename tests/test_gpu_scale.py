@@ -85,6 +85,56 @@ def test_config3_shape_properties(oracle_mod):
     assert torch.equal(torch.cat([a, b]), full)
 
 
+def test_config3_declared_size(oracle_mod):
+    """BASELINE config[2] AT ITS DECLARED SIZE: statistical RLBWT r = 10^9, sigma = 253, Zipf(1.0) heads, mean run 8,
+    seed 3; 10^7 pre-digested reads x 44 minimizer characters, seed 13, half simulated-positive after 4 warm-up characters --
+    the index and the batch of bench.py's headline, through the entry point it times (spx_query_batch_device16 + classes).
+    Oracle on the first 50 000 reads, bit for bit (lengths and the report's columns); partition invariance (ragged split) on all
+    10^7.  What compute_ms_pml.cpp:238-286 computes; needs the whole device (230 GB of index) and ~40 GB of host memory."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, total_mem = torch.cuda.mem_get_info()
+    if total_mem < 250e9 or free < 0.9 * total_mem:
+        pytest.skip("the declared C3 index needs a whole 288 GB device")
+    r, m, nreads = 1_000_000_000, 44, 10_000_000
+    raw = synth.statistical_rlbwt(r, 253, 8.0, seed=3, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, nreads, m, seed=13, positive_fraction=0.5, f_mis=0.02, warmup=4)
+    rawc = raw.cpu()
+    torch.cuda.empty_cache()
+    ix = capi.Index.from_raw(raw, 0)
+    del raw
+    torch.cuda.empty_cache()
+    assert ix.describe()["flat_runs"] >= r
+
+    def pml16(s, o):
+        n = s.numel()
+        d_len = torch.empty(n + 8, dtype=torch.int16, device="cuda")
+        d_cls = torch.empty((o.numel() - 1, 2), dtype=torch.int64, device="cuda")
+        ix.query_device(capi.SPX_MODE_PML, capi.pad_seqs(s), o, n, d_lengths=d_len, d_class=d_cls, bin_width=150, max_value_thr=5)
+        torch.cuda.synchronize()
+        ix.last_stats()
+        return d_len[:n], d_cls
+
+    full, cls = pml16(seqs, offs)
+    st = ix.last_stats()
+    assert st["steps"] == nreads * m
+    ns = 50_000
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    want = orc.pml(seqs[: ns * m].cpu().numpy(), offs[: ns + 1].cpu().numpy())
+    assert np.array_equal(full[: ns * m].cpu().numpy().view(np.uint16).astype(np.uint32), want)
+    f, ab, be, sm = oracle_mod.classify(want, offs[: ns + 1].cpu().numpy(), 150, 5)
+    c32 = cls[:ns].cpu().numpy().view(capi.CLASS_DTYPE).reshape(-1)
+    assert np.array_equal(c32["above"], ab) and np.array_equal(c32["below"], be) and np.array_equal(c32["sum_max"], sm)
+    del orc, rawc
+    k = 3_777_777
+    a, ca = pml16(seqs[: k * m], offs[: k + 1])
+    b, cb = pml16(seqs[k * m:], offs[k:] - offs[k])
+    assert torch.equal(torch.cat([a, b]), full) and torch.equal(torch.cat([ca, cb]), cls)
+    ix.close()
+
+
 def test_config5_long_reads(oracle_mod):
     """BASELINE config[4] shape: few long reads (latency-bound small-batch launch geometry)."""
     raw = synth.statistical_rlbwt(1 << 22, 253, 8.0, seed=6, device="cuda", zipf=1.0)

@@ -96,6 +96,24 @@ def test_many_small_super_batches_on_three_workers(on_fake_device, tmp_path, mon
     T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, [], "-P", fastq=True)
 
 
+def test_default_devices_every_visible_device_twice(on_fake_device, tmp_path, monkeypatch):
+    """Without SPUMONI_GPUS the CLI uses what it sees (the reference's OpenMP region over all threads,
+    compute_ms_pml.cpp:890-1024): one visible device -> three workers on it; several -> every device, two workers each
+    (FAKE_SPX_DEVICES=4: eight workers on devices 0..3, four copies of the index).  Same bytes as the oracle harness."""
+    T = _cli()
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 49, list(b"ACGT"), nreads=600)
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-w", "50"], "-P")
+    assert len([ln for ln in r.stderr.decode().splitlines() if "super-batches" in ln]) == 3
+    monkeypatch.setenv("FAKE_SPX_DEVICES", "4")
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-w", "50"], "-P")
+    batches = [int(ln.split("(")[1].split()[0]) for ln in r.stderr.decode().splitlines() if "super-batches" in ln]
+    assert len(batches) == 8 and sum(batches) >= 16, batches
+    monkeypatch.setenv("SPUMONI_GPUS", "2")  # (the override still rules)
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-w", "50"], "-P")
+    assert len([ln for ln in r.stderr.decode().splitlines() if "super-batches" in ln]) == 1
+
+
 @pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.02"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.6"},
