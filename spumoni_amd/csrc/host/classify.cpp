@@ -1084,6 +1084,14 @@ void finish_batch(Pool& pool, const RunOptions& o, Outputs& out, const SuperBatc
             open_[i] = (res.streams & (1u << i)) && out.f[i].is_open();
             const uint64_t bytes = open_[i] ? res.line_start[i][nreads] : 0;
             const bool fits = open_[i] && out.f[i].map && file_off[i] + bytes <= out.f[i].map_size;
+            if (open_[i] && out.f[i].map && !fits) {
+                // (the tail was prepared from an estimate -- bytes per value by mode, prepare_outputs -- and the run has used it up:
+                // said once per file, so that a long-read run that silently takes the slower way can be seen: ADVICE r5)
+                static std::atomic<unsigned> told{0};
+                if (!(told.fetch_or(1u << i) & (1u << i)))
+                    std::fprintf(stderr, "[spumoni-gpu] note: the prepared tail of output stream %d (%.1f MB, an estimate) is used up after %.1f MB: "
+                                         "the rest is written the ordinary way\n", i, (double)out.f[i].mapped_bytes / 1e6, (double)file_off[i] / 1e6);
+            }
             dest[i] = fits ? out.f[i].map + file_off[i] : nullptr;
             direct[i] = fits && res.text_at[i] == dest[i];  // the device wrote it there
         }
@@ -1306,6 +1314,20 @@ static size_t feeders_for(size_t nworkers) {
 static size_t slots_for(size_t nworkers) { return nworkers + feeders_for(nworkers) + 2; }  // one per worker, one per feeder, two being written
 static double pin_share();
 static uint64_t split_min_bytes();
+static uint64_t mem_available();
+// ONE budget -- a third of what the machine has available when the run starts -- for everything that is prepared ahead of the
+// run and mostly page-locked: the value streams' tails, the report's, the pinned pool.  (Until round 6 each of the three asked
+// /proc/meminfo on its own, while the others were allocating beside it: their sum could exceed what was there.  ADVICE r5.)
+static bool claim_prepared_memory(uint64_t bytes) {
+    static std::atomic<int64_t> left{[] {
+        const uint64_t a = mem_available();
+        return a == ~0ull ? INT64_MAX : (int64_t)(a / 3);
+    }()};
+    if (bytes > (uint64_t)INT64_MAX / 2) return false;
+    if (left.fetch_sub((int64_t)bytes) - (int64_t)bytes >= 0) return true;
+    left.fetch_add((int64_t)bytes);
+    return false;
+}
 void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
     if (spx_device_count() <= 0) return;
     // sized from the reads file, not from the super-batch limit alone: a small file needs small blocks and few
@@ -1341,6 +1363,11 @@ void prepare_pinned_pool(const RunOptions& o, size_t nworkers) {
             if (text_staged || upper_part) sizes.push_back(chars * 3);
             sizes.push_back((reads_guess + 1) * 8);
         }
+    }
+    {
+        uint64_t all = 0;
+        for (size_t b : sizes) all += b;
+        if (!claim_prepared_memory(all)) return;  // (the slots then allocate what they need themselves)
     }
     for (size_t b : sizes) {
         void* p = spx_host_alloc(b);
@@ -1418,30 +1445,65 @@ static void prepare_one(OutputFiles* out, int f, const std::string& final_path, 
     const uint64_t size = (est + 4095) & ~4095ull;
     void* m = MAP_FAILED;
     auto t0 = tick();
-    if (::fallocate(fd, 0, 0, (off_t)size) == 0) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    if (m == MAP_FAILED) {  // (a file system that cannot do either: the file is written the ordinary way)
+    // The file's pages: fallocate makes them (one thread, under the inode's lock: 0.47 s for 8.6 GB on the GPU box), then four
+    // threads make the page table entries (0.23 s).  SPUMONI_PREP=populate (round 6; not the default): the
+    // file is only given its size and the threads that make the entries make the pages with them (MADV_POPULATE_WRITE on a
+    // hole of a tmpfs file allocates and clears the page) -- measured SLOWER the more threads take part, 1.6 / 2.1 / 2.6 / 4.5 s
+    // at 4 / 16 / 32 / 64 threads for the same 8.6 GB: tmpfs page allocation does not scale over cores, and one thread inside
+    // fallocate is the fastest way to 2 * 10^6 pages (profiles/r06_cli_output_preparation.txt).  Either way a file system
+    // that cannot give the estimate shows up here -- fallocate / populate fail -- not as a SIGBUS inside the run, and the file
+    // is written the ordinary way.
+    static const bool by_populate = [] {
+        const char* e = std::getenv("SPUMONI_PREP");
+        return e && std::strcmp(e, "populate") == 0;
+    }();
+    static const unsigned prep_threads = [] {
+        const char* e = std::getenv("SPUMONI_PREP_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return e ? std::max(1, std::atoi(e)) : (int)std::min(16u, std::max(4u, hw / 2));
+    }();
+    const bool sized = by_populate ? ::ftruncate(fd, (off_t)size) == 0 : ::fallocate(fd, 0, 0, (off_t)size) == 0;
+    if (sized) m = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    auto give_up = [&] {  // (a file system that cannot do it, or is full: the file is written the ordinary way)
+        if (m != MAP_FAILED) ::munmap(m, size);
         if (::ftruncate(fd, 0) != 0) { /* (still empty then) */ }
         of.fd = fd;
-        return;
-    }
+    };
+    if (m == MAP_FAILED) return give_up();
     const double s0 = since(t0);
     t0 = tick();
     {
         // the page table entries now, by a few threads, so that nothing faults inside the run
-        const unsigned nt = 4;
+        const unsigned nt = by_populate ? prep_threads : 4;
+        std::atomic<bool> failed{false};
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([=] {
+            th.emplace_back([=, &failed] {
                 const uint64_t lo = (size / 4096 * t / nt) * 4096, hi = t + 1 == nt ? size : (size / 4096 * (t + 1) / nt) * 4096;
 #ifdef MADV_POPULATE_WRITE
-                if (hi > lo && ::madvise((char*)m + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+                // (by pieces: a thread that finds the file system full stops, and the others with it)
+                const uint64_t piece = 64ull << 20;
+                uint64_t a = lo;
+                for (; a < hi && !failed.load(std::memory_order_relaxed); a += piece)
+                    if (::madvise((char*)m + a, std::min(piece, hi - a), MADV_POPULATE_WRITE) != 0) break;
+                if (a >= hi) return;
+                if (failed.load(std::memory_order_relaxed)) return;
+                if (by_populate || errno != EINVAL) {  // (EINVAL: a kernel without MADV_POPULATE_WRITE -- touch the pages instead)
+                    failed.store(true);
+                    return;
+                }
 #endif
-                for (uint64_t a = lo; a < hi; a += 4096) {
-                    volatile char* p = (volatile char*)m + a;
+                if (by_populate) {  // (touching a hole of a full file system would be a SIGBUS)
+                    failed.store(true);
+                    return;
+                }
+                for (uint64_t a2 = lo; a2 < hi; a2 += 4096) {
+                    volatile char* p = (volatile char*)m + a2;
                     *p = *p;
                 }
             });
         for (auto& x : th) x.join();
+        if (failed.load()) return give_up();
     }
     const double s1 = since(t0);
     t0 = tick();
@@ -1508,15 +1570,36 @@ void prepare_outputs(OutputFiles* out, const RunOptions& o, uint64_t reads_file_
             ::close(rfd);
         }
     }
+    // (values grow with the reads: a PML / MS length can have as many digits as the read's length, a 10 kbp read's values are
+    // 4-5 digits where a 200 bp read's are 1-3 -- the first read of the file stands for all: ADVICE r5)
+    double extra_digits = 0;
+    {
+        const int rfd = ::open(o.pattern_file.c_str(), O_RDONLY);
+        if (rfd >= 0) {
+            char head[1 << 16];
+            const ssize_t got = ::read(rfd, head, sizeof head);
+            ::close(rfd);
+            if (got > 0) {
+                const char* nl = (const char*)std::memchr(head, '\n', (size_t)got);
+                size_t len = 0;
+                if (nl) {  // the first record's sequence: up to the next '>' / '+' line (FASTA lines are summed, a FASTQ record has one)
+                    for (const char* p = nl + 1; p < head + got && *p != '>' && *p != '+'; ++p) len += *p != '\n' && *p != '\r';
+                    if (nl + 1 + len >= head + got - 2) len = std::max<size_t>(len, 60000);  // (did not end inside the window: long)
+                }
+                for (size_t t = 1000; t <= len; t *= 10) extra_digits += 1.0;
+            }
+        }
+    }
     const double factor = map_factor();
     // bytes per value: lengths "<1-3 digits> ", pointers "<up to 13 digits> ", document ids "<1-3 digits> "; + the ">id" lines
     uint64_t est[3] = {0, 0, 0};
     const bool report_only = o.report_only && !o.ms && o.write_report;
-    if (!report_only) est[F_LENGTHS] = (uint64_t)(fb * (0.15 + (o.ms ? 3.4 : 2.6) * v) * factor);
+    if (!report_only) est[F_LENGTHS] = (uint64_t)(fb * (0.15 + ((o.ms ? 3.4 : 2.6) + 0.8 * extra_digits) * v) * factor);
     if (o.ms) est[F_POINTERS] = (uint64_t)(fb * (0.15 + 10.5 * v) * factor);
     if (o.use_doc) est[F_DOCS] = (uint64_t)(fb * (0.15 + 2.2 * v) * factor);
-    // (never more than a third of what the machine has free: the estimate is an upper-ish bound, not a promise)
-    if (est[0] + est[1] + est[2] > mem_available() / 3) return;
+    // (never more than a third of what the machine has free -- the budget shared with the report and the pinned pool: the
+    // estimate is an upper-ish bound, not a promise)
+    if (est[0] + est[1] + est[2] == 0 || !claim_prepared_memory(est[0] + est[1] + est[2])) return;
     static const char* const ext[3] = {nullptr, ".pointers", ".doc_numbers"};
     for (int f = 0; f < 3; ++f) {
         if (est[f] == 0 || est[f] < map_min_bytes()) continue;
@@ -1532,7 +1615,7 @@ void prepare_report(OutputFiles* out, const RunOptions& o, uint64_t reads_guess)
     if (!out || !o.write_report || !outputs_can_be_mapped(o)) return;
     const auto t0 = std::chrono::steady_clock::now();
     const uint64_t est = (uint64_t)((double)(reads_guess + 16) * 100.0 * map_factor()) + 256;
-    if (est >= map_min_bytes() && est < mem_available() / 3) prepare_one(out, F_REPORT, o.pattern_file + ".report", est, false);
+    if (est >= map_min_bytes() && claim_prepared_memory(est)) prepare_one(out, F_REPORT, o.pattern_file + ".report", est, false);
     std::lock_guard<std::mutex> g(g_settle_mu);
     out->prepare_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

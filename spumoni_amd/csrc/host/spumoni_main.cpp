@@ -236,6 +236,8 @@ static int run_spumoni(CliOptions& o) {  // run_spumoni_main / run_spumoni_ms_ma
     if (auto_devices > 1 && o.threads <= 1)
         o.format_threads = std::max(1u, std::min(16u * (unsigned)auto_devices, std::thread::hardware_concurrency()));
     if (!reads_err.empty()) fatal_error("%s", reads_err.c_str());
+    // (test-only: hold the run here, the files prepared and nothing processed -- tests/test_host_harness_cpu.py interrupts it)
+    if (const char* e = std::getenv("SPUMONI_TEST_STALL_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(e)));
     DONE_LOG((std::chrono::system_clock::now() - start_time));
     std::cout << std::endl;
     if (o.use_promotions)

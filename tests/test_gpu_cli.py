@@ -531,6 +531,50 @@ def test_cli_four_workers_on_many_small_super_batches(built, tmp_path, monkeypat
         assert "index replica on device" not in err
 
 
+def test_cli_eight_workers_and_eight_feeders_on_a_million_reads(built, tmp_path):
+    """What an 8-GPU node's default looks like to the host, on the one device there is (nothing here has run on
+    two physical devices): SPUMONI_GPUS=0,0,0,0,0,0,0,0 + SPUMONI_FEEDERS=8 -- eight workers (query contexts over one copy of the
+    index) fed by eight parsers from one queue, the ordered completion putting 10^6 reads back in input order (reads are
+    independent: compute_ms_pml.cpp:890-1024).  The files must equal the three-worker default's byte for byte, and the run must not
+    be slower than it (the window of the reference's timer; a generous bound: boxes jitter)."""
+    import re
+
+    raw, text = cases.real_case(61, 300_000, list(b"ACGT"), ndocs=4)
+    ref = str(tmp_path / "ref")
+    open(ref + ".fa", "w").write(">dummy\n")
+    raw.write_raw_files(ref + ".fa")
+    from tests.sdsl_files import write_null_db
+
+    write_null_db(ref + ".fa.pmlnulldb", 4.0, [1, 2, 3, 4, 4, 4, 4, 4])
+    nreads, m = 1_000_000, 200
+    seqs, _ = synth.sample_reads(text, nreads, m, seed=21)
+    rows = seqs.reshape(nreads, m)
+    reads = tmp_path / "reads.fa"
+    with open(reads, "wb") as f:
+        for i in range(0, nreads, 100000):
+            f.write(b"".join(b">read_%d\n" % j + rows[j].tobytes() + b"\n" for j in range(i, min(nreads, i + 100000))))
+
+    def run(env_extra):
+        best, files = None, None
+        for _ in range(2):
+            r = subprocess.run([HOST_BIN, "run", "-r", ref, "-p", str(reads), "-n", "-P", "-c"], capture_output=True,
+                               env=dict(os.environ, SPUMONI_CACHE="off", **env_extra))
+            err = r.stderr.decode()
+            assert r.returncode == 0 and "finished processing 1000000 reads" in err, err[-2000:]
+            secs = [float(x) for x in re.findall(r"done\.\s+\(([0-9.]+) sec\)", err)]
+            best = secs[1] if best is None else min(best, secs[1])
+            files = {e: open(str(reads) + e, "rb").read() for e in (".pseudo_lengths", ".report")}
+        return best, files, err
+
+    t3, f3, _ = run({"SPUMONI_GPUS": "0,0,0"})
+    t8, f8, err8 = run({"SPUMONI_GPUS": "0,0,0,0,0,0,0,0", "SPUMONI_FEEDERS": "8"})
+    assert f8 == f3 and len(f3[".pseudo_lengths"]) > 400_000_000
+    batches = [int(ln.split("(")[1].split()[0]) for ln in err8.splitlines() if "super-batches" in ln]
+    assert len(batches) == 8 and sum(1 for b in batches if b > 0) >= 2, batches
+    assert "8 feeders" in err8, err8[-1500:]
+    assert t8 <= 1.5 * t3 + 0.02, (t8, t3)
+
+
 def _general_text_case(tmp_path, exe):
     """`run -g -n`: the pattern file is raw bytes, every read ends in \x01 and is named read_<k>; no upper-casing; an empty
     read has an empty values line; what follows the last separator is not a read (compute_ms_pml.cpp:1219-1297).  Both

@@ -114,6 +114,96 @@ def test_default_devices_every_visible_device_twice(on_fake_device, tmp_path, mo
     assert len([ln for ln in r.stderr.decode().splitlines() if "super-batches" in ln]) == 1
 
 
+def _limited(limit_bytes):
+    """preexec_fn: no file may grow past limit_bytes; the kernel's SIGXFSZ is ignored, so the calls fail with EFBIG instead"""
+    def fn():
+        import resource
+        import signal
+
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+        resource.setrlimit(resource.RLIMIT_FSIZE, (limit_bytes, limit_bytes))
+    return fn
+
+
+@pytest.mark.parametrize("prep", ["populate", "falloc"])
+def test_prepared_tail_that_cannot_be_had_falls_back_to_plain_writes(on_fake_device, tmp_path, monkeypatch, prep):
+    """the files' tails are prepared from an ESTIMATE (here four times the truth, SPUMONI_MAP_FACTOR=4); where the
+    file system cannot give that much (a full disk; here RLIMIT_FSIZE at twice the real size of the largest file) the preparation
+    fails quietly and the run writes the ordinary way -- same bytes as the oracle harness (compute_ms_pml.cpp:1001-1021), nothing
+    left behind.  Both ways of preparing: SPUMONI_PREP=populate (ftruncate + MADV_POPULATE_WRITE) and falloc (fallocate)."""
+    T = _cli()
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0,0")
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 50, list(b"ACGT"), nreads=400)
+    r = T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-d", "-w", "50"], "-P")
+    gpu = tmp_path / "gpu"
+    real = max(os.path.getsize(gpu / f) for f in os.listdir(gpu))
+    want = {f: open(gpu / f, "rb").read() for f in os.listdir(gpu) if not f.endswith(".fa")}
+    for f in want:
+        os.remove(gpu / f)
+    env = dict(os.environ, SPUMONI_MAP_MIN="1", SPUMONI_MAP_FACTOR="4", SPUMONI_PREP=prep)
+    cmd = [T.HOST_BIN, "run", "-r", ref, "-p", str(gpu / "reads.fa"), "-n", "-P", "-c", "-d", "-w", "50"]
+    r = subprocess.run(cmd, capture_output=True, env=env, preexec_fn=_limited(2 * real))
+    assert r.returncode == 0, r.stderr.decode()
+    err = r.stderr.decode()
+    assert "its tail was prepared as memory" not in [ln for ln in err.splitlines() if "writer lengths" in ln][0], err
+    got = {f: open(gpu / f, "rb").read() for f in os.listdir(gpu) if not f.endswith(".fa")}
+    assert got == want  # (nothing else in the directory either: no *.partial.* left)
+    # ... and with room for the estimate the tail is memory again
+    r = subprocess.run(cmd, capture_output=True, env=env, preexec_fn=_limited(64 * real))
+    assert r.returncode == 0 and "its tail was prepared as memory" in r.stderr.decode()
+    assert {f: open(gpu / f, "rb").read() for f in os.listdir(gpu) if not f.endswith(".fa")} == want
+
+
+def test_leftovers_of_killed_and_interrupted_runs(on_fake_device, tmp_path, monkeypatch):
+    """A run that is killed outright leaves its prepared `<output>.partial.<pid>` behind (nothing of it could clean up): the next run
+    over the same pattern file removes the files of processes that are gone -- and only those.  A run that is interrupted (SIGTERM)
+    removes its own on the way out."""
+    import signal
+    import time
+
+    T = _cli()
+    monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
+    monkeypatch.setenv("SPUMONI_GPUS", "0,0,0")
+    monkeypatch.setenv("SPUMONI_MAP_MIN", "1")
+    ref, prefix, seqs, offs, rng = T._setup(tmp_path, 51, list(b"ACGT"), nreads=400)
+    gpu = tmp_path / "gpu"
+    dead = subprocess.Popen(["true"])
+    dead.wait()
+    stale = [gpu / f"reads.fa.pseudo_lengths.partial.{dead.pid}", gpu / f"reads.fa.report.old.{dead.pid}"]
+    alive = gpu / f"reads.fa.pseudo_lengths.partial.{os.getpid()}"  # (this test's own process: alive)
+
+    def plant():
+        gpu.mkdir(exist_ok=True)
+        for f in stale + [alive]:
+            f.write_bytes(b"x" * 5000)
+
+    # (_run_both recreates the directory: plant the files through a wrapper of the fasta writer it calls)
+    orig = T._write_fasta
+
+    def write_and_plant(path, *a, **k):
+        orig(path, *a, **k)
+        if str(path).startswith(str(gpu)):
+            plant()
+
+    monkeypatch.setattr(T, "_write_fasta", write_and_plant)
+    T._run_both(tmp_path, ref, prefix, "reads.fa", seqs, offs, rng, ["-c", "-w", "50"], "-P")
+    assert not any(f.exists() for f in stale) and alive.exists()
+    alive.unlink()
+    # interrupted: SPUMONI_TEST_STALL_MS holds the run after the files were prepared
+    env = dict(os.environ, SPUMONI_TEST_STALL_MS="3000")
+    p = subprocess.Popen([T.HOST_BIN, "run", "-r", ref, "-p", str(gpu / "reads.fa"), "-n", "-P", "-c"], env=env,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    mine = [gpu / f"reads.fa.pseudo_lengths.partial.{p.pid}", gpu / f"reads.fa.report.partial.{p.pid}"]
+    t0 = time.time()
+    while not mine[0].exists() and time.time() - t0 < 20:
+        time.sleep(0.02)
+    assert mine[0].exists(), "the run did not prepare its files"
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=20) == 128 + signal.SIGTERM
+    assert not any(f.exists() for f in mine)
+
+
 @pytest.mark.parametrize("regime", [{"SPUMONI_MAP_MIN": "1"}, {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.3"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_FACTOR": "0.02"},
                                     {"SPUMONI_MAP_MIN": "1", "SPUMONI_MAP_OUTPUT": "nopin", "SPUMONI_MAP_FACTOR": "0.6"},
