@@ -443,7 +443,7 @@ struct Results {
 // (dest[i] stays null: the slot's page-locked buffer is used and a writer thread copies it).
 using PlaceFn = std::function<void(const uint64_t bytes[3], char* dest[3])>;
 // SPUMONI_CALL_TRACE=1: when every worker entered and left the library (begin = copy in + walk + sizes, fetch = digits + copy
-// out), microseconds on one clock -- who waited for whom on the device (tools/r05_overlap.sh)
+// out), microseconds on one clock -- who waited for whom on the device (profiles/r05_cli_overlap.txt)
 struct CallTrace {
     std::mutex mu;
     struct Rec { const void* ix; const char* what; double t0, t1; };

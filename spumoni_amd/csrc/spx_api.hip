@@ -1258,7 +1258,7 @@ int spx_query_text_begin(spx_index* ix, int mode, int digest_kind, uint32_t k, u
     };
     // SPX_PHASE_TRACE=1: the device's own times of a call's phases (events on the handle's stream, read after the call's one
     // synchronisation: nothing is added to the stream's work) -- how long the copy in / the kernels / the copy out of one
-    // query context take while another context of the same device is at work (tools/r05_overlap.sh)
+    // query context take while another context of the same device is at work (profiles/r05_cli_overlap.txt)
     static const bool phase_trace = getenv("SPX_PHASE_TRACE") != nullptr;
     static thread_local hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};
     auto mark = [&](int i) {
