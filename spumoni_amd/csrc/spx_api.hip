@@ -258,10 +258,16 @@ static int from_runs_impl(spx_index* ix, const uint8_t* heads, const uint64_t* l
             dev[i] = t[i].p;
         }
     }
+    // (host arrays: the device copies are this function's own and are given back before the fat table is sized)
     int rc = flatten_on_device(ix, (const uint8_t*)dev[0], (const uint64_t*)dev[1],
                                (const uint64_t*)dev[2], (const uint64_t*)dev[3],
                                (const uint64_t*)dev[4], (const uint64_t*)dev[5],
-                               (const uint64_t*)dev[6]);
+                               (const uint64_t*)dev[6], [&] {
+                                   for (Tmp& x : t) {
+                                       if (x.p) (void)hipFree(x.p);
+                                       x.p = nullptr;
+                                   }
+                               });
     if (rc != SPX_OK) return rc;
     return init_runtime(ix);
 }

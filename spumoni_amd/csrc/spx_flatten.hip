@@ -8,6 +8,8 @@
 // 10^9-run index is laid out in seconds without touching the host.
 #include <hipcub/hipcub.hpp>
 
+#include <functional>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -529,7 +531,7 @@ __global__ void k_piece_fill(const uint8_t* heads, const uint64_t* lens, const u
 
 static int flatten_core(spx_index* ix, uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
                         const uint64_t* d_ssa, const uint64_t* d_esa, const uint64_t* d_ds, const uint64_t* d_de,
-                        const uint8_t* d_cont);
+                        const uint8_t* d_cont, const std::function<void()>& release_inputs);
 
 namespace {
 
@@ -599,9 +601,11 @@ int images_of_runs(const RunList& in, DevBuf& Sb, DevBuf& LFk, bool& ok, hipStre
 
 }  // namespace
 
+// release_inputs (may be empty): frees the caller's device copies of the raw arrays; called once, when nothing reads them any
+// more and BEFORE the fat table is sized -- an index loaded from files gives the table the memory its raw arrays held
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
-                      const uint64_t* d_ds, const uint64_t* d_de) {
+                      const uint64_t* d_ds, const uint64_t* d_de, const std::function<void()>& release_inputs) {
     const uint64_t r = ix->r;
     if (r == 0 || r > 0xfffffff0ull) {
         set_error("number of runs %llu out of range (1 .. 2^32-16)", (unsigned long long)r);
@@ -633,7 +637,12 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
     orig.esa = d_esa;
     orig.ds = d_ds;
     orig.de = d_de;
-    auto as_it_is = [&] { return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr); };
+    bool released = false;
+    auto release_once = [&] {
+        if (!released && release_inputs) release_inputs();
+        released = true;
+    };
+    auto as_it_is = [&] { return flatten_core(ix, r, d_heads, d_lens, d_thr, d_ssa, d_esa, d_ds, d_de, nullptr, release_once); };
     if (getenv("SPX_ROWS_WIDE") || getenv("SPX_NO_PIECES") || (max_len <= PIECE_MAX && !want_balance)) return as_it_is();
     const bool timing = getenv("SPX_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -729,17 +738,22 @@ int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_l
         next.de = cur.de ? g.de.as<uint64_t>() : nullptr;
         next.cont = g.c.as<uint8_t>();
         cur = next;
+        if (pass == 0) release_once();  // (the caller's arrays: every later pass reads a generation of pieces)
         gen[(pass + 1) & 1].release();  // the generation this one was cut from
         if (!balance) break;            // (pieces for length only: nothing a further pass would change)
         // (Sb, LFk, pieces, ... go out of scope here: the table flatten_core builds sizes itself against free memory)
     }
     if (cur.cont == nullptr) return as_it_is();
-    return flatten_core(ix, cur.r, cur.heads, cur.lens, cur.thr, cur.ssa, cur.esa, cur.ds, cur.de, cur.cont);
+    // (the last generation of pieces is this function's own: gone, like the caller's arrays, before the table is sized)
+    return flatten_core(ix, cur.r, cur.heads, cur.lens, cur.thr, cur.ssa, cur.esa, cur.ds, cur.de, cur.cont, [&] {
+        gen[0].release();
+        gen[1].release();
+    });
 }
 
 static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads, const uint64_t* d_lens, const uint64_t* d_thr,
                         const uint64_t* d_ssa, const uint64_t* d_esa, const uint64_t* d_ds, const uint64_t* d_de,
-                        const uint8_t* d_cont) {
+                        const uint8_t* d_cont, const std::function<void()>& release_inputs) {
     if (r == 0 || r > 0xfffffff0ull) {
         set_error("number of runs %llu out of range (1 .. 2^32-16)", (unsigned long long)r);
         return SPX_E_FORMAT;
@@ -873,6 +887,45 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     (void)hipFree(LFs.p);
     LFs.p = nullptr;
 
+    // Everything but the fat table first -- the directory, the samples and document ids by directory position, the scalars of
+    // the initial state -- so that the table, which takes whatever memory is left within the budget, is sized when the
+    // temporaries of this function (14 B per run, 38 with samples) and the caller's copies of the raw arrays are gone
+    // (round 6: the declared C4, flattened beside 50 GB of raw arrays and 18 GB of temporaries, got 3.3 slots per run where
+    // its budget allows 4.2).
+    SPX_ALLOC0(ix->q_alloc, (r + 1 + Q_PAD) * 4);
+    k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
+                                                                         ix->q_alloc);
+    uint64_t bytes = (r + ROW_PAD) * (row_bytes + sizeof(JumpRow)) + (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) +
+                     (docs ? (r + ROW_PAD) * 4 : 0);
+    uint64_t last_esa = 0, last_de = 0, first_ds = 0;
+    DevBuf samples_tmp;
+    if (d_ssa && d_esa) {
+        SPX_HIP(samples_tmp.alloc((r + 2) * sizeof(SamplePair)));
+        SPX_ALLOC0(ix->ss_by_run, (r + 4) * 8);
+        k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, samples_tmp.as<SamplePair>(),
+                                                   ix->ss_by_run);
+        SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        bytes += (r + 4) * 8;
+        ix->has_samples = true;
+    }
+    ix->has_docs = docs;
+    if (ix->has_samples || docs) {  // samples + doc words of a directory position in one record
+        SPX_ALLOC0(ix->aux, (r + 2) * sizeof(Aux));
+        k_pack_aux<<<nblocks(r + 1), TPB, 0, st>>>(ix->has_samples ? samples_tmp.as<SamplePair>() : nullptr,
+                                                    docs ? dirdocs_tmp.as<uint32_t>() : nullptr, r + 1, ix->aux);
+        bytes += (r + 2) * sizeof(Aux);
+    }
+    if (docs) {
+        SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
+        SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
+    }
+    const bool has_ms = d_ssa && d_esa;
+    SPX_HIP(hipStreamSynchronize(st));
+    for (DevBuf* t : {&samples_tmp, &dirdocs_tmp, &Qall, &S, &Hs, &H, &tmp}) {
+        if (t->p) (void)hipFree(t->p);
+        t->p = nullptr;
+    }
+    if (release_inputs) release_inputs();  // (d_heads .. d_de are not read past this line)
     // Fat-table geometry = how much HBM is traded for speed.  A fat slot answers a jump outright
     // when no c-run lies between its block's start and the walk's run, so smaller blocks mean fewer
     // fat_js / Q / dirrow gathers (measured on C3, same box, uniform blocks: 884 / 975 / 1 051 /
@@ -888,7 +941,6 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     // the index is a few GB.)
     size_t mem_free = 0, mem_total = 0;
     SPX_HIP(hipMemGetInfo(&mem_free, &mem_total));
-    const bool has_ms = d_ssa && d_esa;
     const uint32_t fat_row_bytes = sizeof(FatRow);
     // SPX_FAT_LROW=1: a PML-only index with compact rows keeps the landing run's row in its fat slots (32-byte slots, half
     // as many of them for the same budget; profiles/r04_fat_lrow.txt)
@@ -898,9 +950,8 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     const double per_slot = fat_stride + 4.0 / FJ_GROUP /* fat_js */;
     // per-run arrays: rows 16 / 32 + dirrows 32 + Q 4 (+ aux 16, ss_by_run 8, rundocs 4)
     const double fixed = (double)r * ((double)row_bytes + 32 + 4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 : 0) + (docs ? 4 : 0));
-    // still to be allocated from the free memory besides the fat table: Q, aux, ss_by_run and the
-    // sample pairs scratch
-    const double to_come = (double)r * (4 + ((has_ms || docs) ? 16 : 0) + (has_ms ? 8 + 16 : 0)) + (64 << 20);
+    // (everything else of the index is allocated by now: the table shares what is free with nothing but the caller)
+    const double to_come = (double)(64 << 20);
     double budget = 0.75 * (double)mem_total;
     if (const char* e = getenv("SPX_INDEX_BUDGET_GB")) budget = atof(e) * 1e9;
     double fat_bytes = budget - fixed;
@@ -953,29 +1004,7 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
     }
     const uint64_t nfat = (uint64_t)geometry(K, true);
     SPX_HIP(hipMemcpyAsync(ix->letters, hl.data(), 256 * sizeof(LetterInfo), hipMemcpyHostToDevice, st));
-    SPX_ALLOC0(ix->q_alloc, (r + 1 + Q_PAD) * 4);
-    k_copy_q<<<nblocks(r > (uint64_t)Q_PAD ? r : Q_PAD), TPB, 0, st>>>(Qall.as<uint32_t>(), r,
-                                                                         ix->q_alloc);
-    uint64_t bytes = (r + ROW_PAD) * (row_bytes + sizeof(JumpRow)) + (nfat + 2) * (uint64_t)fat_stride +
-                     (r + 1 + Q_PAD) * 4 + 256 * sizeof(LetterInfo) + (docs ? (r + ROW_PAD) * 4 : 0);
-    uint64_t last_esa = 0, last_de = 0, first_ds = 0;
-    DevBuf samples_tmp;
-    if (d_ssa && d_esa) {
-        SPX_HIP(samples_tmp.alloc((r + 2) * sizeof(SamplePair)));
-        SPX_ALLOC0(ix->ss_by_run, (r + 4) * 8);
-        k_samples<<<nblocks(r + 1), TPB, 0, st>>>(d_ssa, d_esa, Qall.as<uint32_t>(), r, samples_tmp.as<SamplePair>(),
-                                                   ix->ss_by_run);
-        SPX_HIP(hipMemcpyAsync(&last_esa, d_esa + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        bytes += (r + 4) * 8;
-        ix->has_samples = true;
-    }
-    ix->has_docs = docs;
-    if (ix->has_samples || docs) {  // samples + doc words of a directory position in one record
-        SPX_ALLOC0(ix->aux, (r + 2) * sizeof(Aux));
-        k_pack_aux<<<nblocks(r + 1), TPB, 0, st>>>(ix->has_samples ? samples_tmp.as<SamplePair>() : nullptr,
-                                                    docs ? dirdocs_tmp.as<uint32_t>() : nullptr, r + 1, ix->aux);
-        bytes += (r + 2) * sizeof(Aux);
-    }
+    bytes += (nfat + 2) * (uint64_t)fat_stride;
     // the fat table: built from the arrays above (also what spx_index_load_flat does instead of reading it)
     ix->view.nletters = nletters;
     ix->view.nfat = nfat;
@@ -987,10 +1016,6 @@ static int flatten_core(spx_index* ix, const uint64_t r, const uint8_t* d_heads,
         if (rc_fat != SPX_OK) return rc_fat;
     }
     bytes += fatjs_count(nfat) * 4 + 64;
-    if (docs) {
-        SPX_HIP(hipMemcpyAsync(&last_de, d_de + (r - 1), 8, hipMemcpyDeviceToHost, st));
-        SPX_HIP(hipMemcpyAsync(&first_ds, d_ds, 8, hipMemcpyDeviceToHost, st));
-    }
 
     SPX_HIP(hipGetLastError());  // a kernel of this function that failed to launch
     unsigned long long herr = 0;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <string>
 
@@ -269,7 +270,7 @@ int launch_text_from_index(spx_index* ix, uint8_t* d_text, uint64_t n_text, unsi
 // that already live on the device.
 int flatten_on_device(spx_index* ix, const uint8_t* d_heads, const uint64_t* d_lens,
                       const uint64_t* d_thr, const uint64_t* d_ssa, const uint64_t* d_esa,
-                      const uint64_t* d_ds, const uint64_t* d_de);
+                      const uint64_t* d_ds, const uint64_t* d_de, const std::function<void()>& release_inputs = {});
 // spx_walk.hip
 // *wrote_lengths: the walk wrote the PML lengths itself (k_walk_fast): launch_len_expand is not needed
 int launch_walk(spx_index* ix, int mode, const BatchArgs& args, uint64_t total_chars,
