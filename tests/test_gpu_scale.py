@@ -269,6 +269,52 @@ def test_config4_scale_ms_doc(oracle_mod):
     assert torch.equal(ps, ptr[src]) and torch.equal(ds, doc[src])
 
 
+def test_config4_declared_size(oracle_mod):
+    """BASELINE config[3] AT ITS DECLARED SIZE: the C3 index (r = 10^9, seed 3) + SA samples + 10 documents, 5 * 10^6 reads
+    x 55 minimizer characters (250 bp), MS pointers (u64) + document ids (u16) -- bench.py's c4_ms_doc leg as a test.  Oracle on the
+    first 20 000 reads, bit for bit (compute_ms_pml.cpp:626-682); partition invariance (ragged split) on all 5 * 10^6.  MS LENGTHS need a
+    text, which a statistical index does not have: test_config2 / the parity tests / real_bwt_ms_doc cover them."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, total_mem = torch.cuda.mem_get_info()
+    if total_mem < 250e9 or free < 0.9 * total_mem:
+        pytest.skip("the declared C4 index needs a whole 288 GB device")
+    r, m, nreads = 1_000_000_000, 55, 5_000_000
+    raw = synth.statistical_rlbwt(r, 253, 8.0, seed=3, device="cuda", zipf=1.0, with_samples=True, n_docs=10)
+    seqs, offs = synth.simulate_reads(raw, nreads, m, seed=14, positive_fraction=0.5, f_mis=0.02, warmup=4)
+    rawc = raw.cpu()
+    torch.cuda.empty_cache()
+    ix = capi.Index.from_raw(raw, 0)
+    del raw
+    torch.cuda.empty_cache()
+    d = ix.describe()
+    assert d["has_samples"] and d["has_docs"] and d["fat_stride"] == 32
+
+    def ms16(s, o):
+        n = s.numel()
+        d_ptr = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_doc = torch.empty(n + 8, dtype=torch.int16, device="cuda")
+        ix.query_device(capi.SPX_MODE_MS, capi.pad_seqs(s), o, n, d_pointers=d_ptr, d_docs=d_doc)
+        torch.cuda.synchronize()
+        ix.last_stats()
+        return d_ptr, d_doc[:n]
+
+    ptr, doc = ms16(seqs, offs)
+    ns = 20_000
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    w = orc.ms(seqs[: ns * m].cpu().numpy(), offs[: ns + 1].cpu().numpy(), want_docs=True)
+    assert np.array_equal(ptr[: ns * m].cpu().numpy().view(np.uint64), w["pointers"])
+    assert np.array_equal(doc[: ns * m].cpu().numpy().view(np.uint16).astype(np.uint32), w["docs"])
+    del orc, rawc
+    k = 1_777_777
+    pa, da = ms16(seqs[: k * m], offs[: k + 1])
+    pb, db = ms16(seqs[k * m:], offs[k:] - offs[k])
+    assert torch.equal(torch.cat([pa, pb]), ptr) and torch.equal(torch.cat([da, db]), doc)
+    ix.close()
+
+
 def test_config5_scale_long_reads_chunked(oracle_mod):
     """BASELINE config[4] shape at scale: 50 000 reads of 2 200 minimizer characters (10 kbp at the digestion
     density) and the per-GPU share of 6 250, statistical index r = 2^27.  Such batches take the chunked walk

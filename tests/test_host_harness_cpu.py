@@ -130,7 +130,7 @@ def test_prepared_tail_that_cannot_be_had_falls_back_to_plain_writes(on_fake_dev
     """the files' tails are prepared from an ESTIMATE (here four times the truth, SPUMONI_MAP_FACTOR=4); where the
     file system cannot give that much (a full disk; here RLIMIT_FSIZE at twice the real size of the largest file) the preparation
     fails quietly and the run writes the ordinary way -- same bytes as the oracle harness (compute_ms_pml.cpp:1001-1021), nothing
-    left behind.  Both ways of preparing: SPUMONI_PREP=populate (ftruncate + MADV_POPULATE_WRITE) and falloc (fallocate)."""
+    left behind.  Both ways of preparing: SPUMONI_PREP=populate (ftruncate + MADV_POPULATE_WRITE) and falloc (fallocate: the default)."""
     T = _cli()
     monkeypatch.setenv("SPUMONI_SUPER_BATCH", "3000")
     monkeypatch.setenv("SPUMONI_GPUS", "0,0,0")

@@ -74,12 +74,16 @@ def run(tag, reads, extra_env):
 
 run("raw index files, SPUMONI_CACHE=write", f"{d}/reads.fa", {"SPUMONI_CACHE": "write"})
 run("flat-layout cache (default: SPUMONI_GPUS=0,0,0 -- three workers, one copy of the index)", f"{d}/reads.fa", {})
-if os.environ.get("E2E_PREP_AB"):  # round 6: how the output files' pages are had (classify.cpp, prepare_one), interleaved twice
-    for rep in (1, 2):
-        run("SPUMONI_PREP=falloc (round 5: fallocate, then 4 threads make the page table entries)", f"{d}/reads.fa", {"SPUMONI_PREP": "falloc"})
-        for nt in (4, 8, 16, 32, 64):
-            run(f"SPUMONI_PREP=populate, {nt} threads (ftruncate; MADV_POPULATE_WRITE makes pages and entries)", f"{d}/reads.fa",
-                {"SPUMONI_PREP": "populate", "SPUMONI_PREP_THREADS": str(nt)})
+if os.environ.get("E2E_PREP_AB"):  # round 6: how the output files' pages are had (classify.cpp, prepare_one), interleaved
+    modes = os.environ["E2E_PREP_AB"].split(",") if "," in os.environ["E2E_PREP_AB"] else ["falloc", "populate:4", "populate:16", "populate:64"]
+    what = {"falloc": "the default: fallocate, THEN 4 threads make the page table entries", "populate": "ftruncate; MADV_POPULATE_WRITE makes pages and entries"}
+    for rep in range(int(os.environ.get("E2E_PREP_REPS", "2"))):
+        for md in modes:
+            name, _, nt = md.partition(":")
+            env = {"SPUMONI_PREP": name}
+            if nt:
+                env["SPUMONI_PREP_THREADS"] = nt
+            run(f"SPUMONI_PREP={md} ({what[name]})", f"{d}/reads.fa", env)
     sys.exit(0)
 quick = os.environ.get("E2E_QUICK") is not None  # (only the first two runs of the PML block)
 run("flat-layout cache, again", f"{d}/reads.fa", {})

@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-# after "the table is sized last" (round 6): the C4 leg's slots per run and speed, round 5's library beside it; then the headline
-AB_REPS=2 AB_LEGS=c4_ms_doc bash tools/ab.sh 2>&1 | cut -c1-900
+for n in 10000000 16000000; do
+E2E_READS=$n E2E_PREP_AB=falloc,pipe E2E_PREP_REPS=3 E2E_CPU_READS=1000 python tools/cli_e2e.py 2>&1 | grep "^== \|files prepared" | cut -c1-420
+done
