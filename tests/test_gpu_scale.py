@@ -342,6 +342,47 @@ def test_config5_scale_long_reads_chunked(oracle_mod):
     ix.set_option("chunk_mode", 0)
 
 
+def test_config5_declared_size(oracle_mod):
+    """BASELINE config[4] AT ITS DECLARED SIZE: statistical RLBWT r = 2 * 10^9 (the 20-haplotype index), seed 6; 50 000
+    reads x 2 200 minimizer characters (10 kbp at the digestion density), seed 17, and the per-GPU share of 6 250 -- bench.py's
+    long_reads_c5 leg as a test.  The chunked walk (what such batches take by themselves) against the plain walk of the same batch,
+    bit for bit over the whole batch (lengths and classes); the oracle on the first 400 reads (compute_ms_pml.cpp:238-286)."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, total_mem = torch.cuda.mem_get_info()
+    if total_mem < 250e9 or free < 0.9 * total_mem:
+        pytest.skip("the declared C5 index needs a whole 288 GB device")
+    r = 2_000_000_000
+    raw = synth.statistical_rlbwt(r, 253, 8.0, seed=6, device="cuda", zipf=1.0)
+    seqs, offs = synth.simulate_reads(raw, 56_250, 2200, seed=17, positive_fraction=0.5, f_mis=0.02, warmup=4)
+    rawc = raw.cpu()
+    torch.cuda.empty_cache()
+    ix = capi.Index.from_raw(raw, 0)
+    del raw
+    torch.cuda.empty_cache()
+    assert ix.describe()["flat_runs"] >= r
+    orc = oracle_mod.OracleIndex.from_raw(rawc)
+    del rawc
+    for lo_r, hi_r in ((0, 6_250), (6_250, 56_250)):
+        s = seqs[lo_r * 2200: hi_r * 2200].contiguous()
+        o = (offs[lo_r: hi_r + 1] - offs[lo_r]).contiguous()
+        ix.set_option("chunk_mode", 0)
+        got, cls = _pml_dev(ix, s, o, classify=(150, 5))
+        cs = ix.last_chunk_stats()
+        assert cs["chunk_len"] >= 128, "a long-read batch must take the chunked walk"
+        assert cs["fallback_reads"] <= (hi_r - lo_r) // 1000
+        ix.set_option("chunk_mode", 1)
+        want, wcls = _pml_dev(ix, s, o, classify=(150, 5))
+        assert torch.equal(got, want) and torch.equal(cls, wcls)
+        ns = 200
+        w = orc.pml(s[: ns * 2200].cpu().numpy(), o[: ns + 1].cpu().numpy())
+        assert np.array_equal(got[: ns * 2200].cpu().numpy().view(np.uint32), w)
+    ix.set_option("chunk_mode", 0)
+    ix.close()
+
+
 def _dev_raw(rawc):
     """the raw arrays back on the device (simulate_reads runs where they live)"""
     kw = {}
